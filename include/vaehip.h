@@ -1,0 +1,181 @@
+/* libvaehip.so -- C ABI of the MI355X (gfx950) SDXL-VAE train-step hot path.
+ *
+ * The reference (olegroshka/vae-channel-dynamics) has no native code; the
+ * boundary it sits behind is the Python object protocol of
+ *   src/models/sdxl_vae_wrapper.py:42-77   (SDXLVAEWrapper.forward)
+ *   src/train.py:283-306                   (step body: loss, backward, clip, AdamW)
+ *   src/tracking/monitor.py:56-80          (per-channel mean|A| tracker)
+ * and every numerically heavy call goes into torch/diffusers library kernels.
+ * Each entry point below names the library op(s) at the reference call site it
+ * replaces.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative VAE_E* code otherwise;
+ *     vae_last_error() returns a thread-local message for the last failure.
+ *   - all pointers are DEVICE pointers owned by the caller (PyTorch allocator);
+ *     nothing is allocated, freed or synchronised inside; every call only
+ *     enqueues work on `stream` (a hipStream_t passed as void*).
+ *   - activations are NHWC fp32: [B][H][W][C], C contiguous.
+ *   - conv / linear weights are OHWI fp32: [Cout][KH][KW][Cin] (this is the
+ *     memory of an nn.Conv2d weight in torch.channels_last layout, and of an
+ *     nn.Linear weight as is), read live every call -- no packed copies.
+ */
+#ifndef VAEHIP_H
+#define VAEHIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VAE_OK 0
+#define VAE_EINVAL (-1)   /* shape / pointer / alignment check failed */
+#define VAE_ELAUNCH (-2)  /* hip launch error */
+
+const char* vae_last_error(void);
+int vae_abi_version(void);
+
+/* input transform applied to the A operand while it is staged into LDS */
+#define VAE_XF_NONE 0
+#define VAE_XF_AFFINE 1      /* x*scale[b][c]+shift[b][c]            (GroupNorm, no activation) */
+#define VAE_XF_AFFINE_SILU 2 /* silu(x*scale[b][c]+shift[b][c])      (GroupNorm + SiLU)         */
+
+/* how a row (b,y,x) of the GEMM maps onto the source tensor */
+#define VAE_MODE_FWD 0   /* sy = y*stride + kh - pad_t                          */
+#define VAE_MODE_UP2X 1  /* source is virtually nearest-upsampled 2x, 3x3 pad 1 */
+#define VAE_MODE_DGRAD 2 /* sy = (y + pad_t - kh)/stride when divisible         */
+
+typedef struct vae_conv_geom {
+  int32_t B, Hs, Ws, Cs; /* source tensor [B][Hs][Ws][Cs]                         */
+  int32_t Ho, Wo;        /* row grid: GEMM row m = (b, y<Ho, x<Wo)                */
+  int32_t taps;          /* 1 (1x1 / linear / plain GEMM) or 9 (3x3)              */
+  int32_t stride;        /* 1 or 2                                                */
+  int32_t pad_t, pad_l;  /* top/left padding (bottom/right is implied by bounds)  */
+  int32_t mode;          /* VAE_MODE_*                                            */
+} vae_conv_geom;
+
+/* C[z][m][n] = sum_{tap,k} XF(A[z][row(m,tap)][k]) * W[z][n*sn + k*sk + tap*st]
+ *              (+ bias[n]) (+ res[z][m][n])
+ * replaces: conv2d fwd (K1,K5), conv2d dgrad (K7), linear fwd/dgrad and the
+ * attention bmm's Q.K^T, P.V, dO.V^T, dS.K (K3,K7).
+ * sk==1 selects the "k-contiguous" weight tile (forward); sn==1 the
+ * "n-contiguous" one (dgrad / P.V).  Exactly one of them must be 1.
+ * track (optional): partial sums of |C| per column, [ceil(M/128)][N] per z==0
+ * (conv only; used for the fused ActivityMonitor metric, monitor.py:66).       */
+typedef struct vae_igemm_args {
+  const float* A; const float* W; float* C;
+  const float* bias; const float* res;
+  const float* scale; const float* shift; /* [B][Cs] when xf != NONE */
+  float* track;
+  vae_conv_geom g;
+  int32_t M, N, K;       /* K = channels per tap actually contracted (<= Cs)      */
+  int32_t ldc;           /* row stride of C and res                               */
+  int64_t sn, sk, st;    /* weight element strides                                */
+  int32_t batch;         /* grid.z; 1 for conv                                    */
+  int64_t sAb, sWb, sCb; /* per-batch element strides (attention)                 */
+  int32_t xf;            /* VAE_XF_*                                              */
+  float alpha;           /* C = alpha * acc (+bias+res); 1.0 for conv             */
+} vae_igemm_args;
+int vae_igemm_rows(const vae_igemm_args* a, void* stream);
+
+/* dW[z][split][m][tap][n] = sum_{pix in split} dY[z][pix][m] * XF(X[z][row(pix,tap)][n])
+ * replaces: conv2d wgrad, linear wgrad, attention P^T.dO and dS^T.Q (K7).
+ * When nsplit==1 the result goes straight to `out` (ld = taps*N); otherwise to
+ * `partial` ([nsplit][M][taps][N]) and the caller runs vae_reduce_splits.      */
+typedef struct vae_wgrad_args {
+  const float* dY; const float* X; float* out; float* partial;
+  const float* scale; const float* shift;
+  vae_conv_geom g;       /* row grid = output pixels of the conv; source = X      */
+  int32_t M, N;          /* M = Cout (cols of dY used), N = Cin (<= g.Cs)         */
+  int32_t ldy;           /* row stride of dY                                      */
+  int32_t npix;          /* contraction length = B*Ho*Wo                          */
+  int32_t nsplit;
+  int32_t batch; int64_t sYb, sXb, sOb;
+  int32_t xf;
+  float alpha;
+} vae_wgrad_args;
+int vae_wgrad(const vae_wgrad_args* a, void* stream);
+/* out[i] = sum_s partial[s][i], fixed order (deterministic)                     */
+int vae_reduce_splits(const float* partial, int32_t nsplit, int64_t n, float* out, void* stream);
+/* colsum: out[c] = sum_rows X[r][c]  (conv / linear bias gradient) two-stage deterministic;
+ * ws needs ceil(rows/1024)*C floats.                                             */
+int vae_colsum(const float* X, int64_t rows, int32_t C, float* ws, float* out, void* stream);
+
+/* ---- GroupNorm (32 groups, eps 1e-6) replaces group_norm fwd/bwd (K2,K7) ---- */
+/* stage 1: per (b, chunk, group) partial sum / sumsq.  ws: [B][nchunk][G][2]     */
+int vae_gn_stats_partial(const float* x, int32_t B, int32_t HW, int32_t C, int32_t G,
+                         int32_t nchunk, float* ws, void* stream);
+/* stage 2: mean/rstd [B][G] and the fused affine scale/shift [B][C]:
+ *   scale = rstd*gamma, shift = beta - mean*rstd*gamma                            */
+int vae_gn_stats_final(const float* ws, int32_t B, int32_t HW, int32_t C, int32_t G, int32_t nchunk,
+                       const float* gamma, const float* beta, float eps,
+                       float* mean, float* rstd, float* scale, float* shift, void* stream);
+/* y = XF(x) materialised (only for layers with foreign hooks / full maps)        */
+int vae_gn_apply(const float* x, const float* scale, const float* shift, int32_t B, int32_t HW,
+                 int32_t C, int32_t xf, float* y, void* stream);
+/* tracker (monitor.py:66): partial sums of |x*scale+shift| per (b,chunk,c);
+ * ws [B][nchunk][C]; then vae_track_final                                         */
+int vae_gn_track_partial(const float* x, const float* scale, const float* shift, int32_t B, int32_t HW,
+                         int32_t C, int32_t nchunk, float* ws, void* stream);
+/* out[c] = (sum over rows of ws[r][c]) * inv_count ; fixed order                   */
+int vae_track_final(const float* ws, int32_t rows, int32_t C, float inv_count, float* out, void* stream);
+/* GroupNorm(+SiLU) backward.  g = dL/d(XF(gn(x))).
+ * stage 1: ws [B][nchunk][C][2] partial sums of du and du*xhat                     */
+int vae_gn_bwd_partial(const float* x, const float* g, const float* mean, const float* rstd,
+                       const float* gamma, const float* beta, int32_t B, int32_t HW, int32_t C, int32_t G,
+                       int32_t nchunk, int32_t silu, float* ws, void* stream);
+/* stage 2: dgamma/dbeta [C] (written, not accumulated) and coefficients
+ * coef [B][G][2] = {rstd*s2/N, rstd*s1/N}                                           */
+int vae_gn_bwd_final(const float* ws, const float* rstd, const float* gamma, int32_t B, int32_t HW,
+                     int32_t C, int32_t G, int32_t nchunk, float* dgamma, float* dbeta, float* coef,
+                     void* stream);
+/* stage 3: dx = du*rstd*gamma - xhat*coef0 - coef1 (+ add)                          */
+int vae_gn_bwd_apply(const float* x, const float* g, const float* mean, const float* rstd,
+                     const float* gamma, const float* beta, const float* coef, const float* add,
+                     int32_t B, int32_t HW, int32_t C, int32_t G, int32_t silu, float* dx, void* stream);
+
+/* ---- attention softmax (K3) ---- */
+int vae_softmax_rows(float* S, int64_t rows, int32_t cols, void* stream);           /* in place */
+/* dS = P*(dP - rowsum(dP*P)) in place on dP                                        */
+int vae_softmax_bwd_rows(const float* P, float* dP, int64_t rows, int32_t cols, void* stream);
+
+/* ---- posterior sample + KL + MSE (K4,K6; train.py:289-291) ---- */
+/* moments [B][hw][2*L] -> z [B][hw][L] = mu + exp(.5*clamp(lv,-30,20))*eps (eps may be null => mode())
+ * kl_partial [B][nblk] ; nblk = ceil(hw*L/256)                                       */
+int vae_sample_kl(const float* moments, const float* eps, int32_t B, int32_t hw, int32_t L,
+                  float* z, float* kl_partial, void* stream);
+/* scalars[0]=mse(mean) [1]=kl(mean over b) [2]=total ; deterministic finalisation   */
+int vae_mse_partial(const float* recon, const float* target, int64_t n, float* ws, int32_t nblk, void* stream);
+int vae_loss_final(const float* mse_ws, int32_t mse_nblk, int64_t mse_n, const float* kl_partial,
+                   int32_t B, int32_t kl_nblk, float kl_weight, float* scalars, void* stream);
+/* d(total)/d(recon) = 2*(recon-target)/n                                             */
+int vae_mse_bwd(const float* recon, const float* target, int64_t n, float* drecon, void* stream);
+/* d(total)/d(moments) from dz and the KL term                                        */
+int vae_sample_kl_bwd(const float* moments, const float* eps, const float* dz, int32_t B, int32_t hw,
+                      int32_t L, float kl_weight, float* dmoments, void* stream);
+
+/* ---- layout / misc ---- */
+int vae_nchw_to_nhwc(const float* src, int32_t B, int32_t C, int32_t HW, int32_t Cpad, float* dst, void* stream);
+int vae_nhwc_to_nchw(const float* src, int32_t B, int32_t C, int32_t HW, float* dst, void* stream);
+/* dst[b][y][x][c] = sum of the 2x2 block of src[b][2y..][2x..][c] (dgrad of nearest-up2x) */
+int vae_sumpool2x2(const float* src, int32_t B, int32_t H, int32_t W, int32_t C, float* dst, void* stream);
+int vae_add(const float* a, const float* b, int64_t n, float* out, void* stream);
+
+/* ---- optimizer (K8,K9; train.py:184-187,301-302) ---- */
+/* sum of squares of g[0..n): stage 1 -> ws[nblk], stage 2 -> out[0]                   */
+int vae_sqnorm(const float* g, int64_t n, float* ws, int32_t nblk, float* out, void* stream);
+/* clip coefficient min(1, max_norm/(sqrt(*sqnorm)+1e-6)) is read from device memory
+ * (max_norm <= 0 disables clipping) then torch.optim.AdamW math, one pass over p,g,m,v */
+int vae_adamw(float* p, const float* g, float* m, float* v, int64_t n, const float* sqnorm,
+              float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
+              int32_t step, void* stream);
+/* dead-weight scan (deadneuron.py:78-115): counts per segment of |w|<thr, and sum|w|;
+ * seg_off [nseg+1] element offsets into w; out_counts [nseg] (u64), out_abssum [nseg] (double) */
+int vae_dead_scan(const float* w, const int64_t* seg_off, int32_t nseg, float thr,
+                  unsigned long long* out_counts, double* out_abssum, void* stream);
+int vae_dead_scan_adaptive(const float* w, const int64_t* seg_off, int32_t nseg, float thr, int32_t use_fixed,
+                           const float* adaptive_thr, unsigned long long* out_counts, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

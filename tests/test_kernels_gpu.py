@@ -1,0 +1,279 @@
+"""Per-kernel parity: every HIP entry point (through the C ABI) against a plain PyTorch fp32
+CPU reference of the same op, on seeded inputs.  Tolerances: fp32 MFMA is an exact-product
+fp32 fmaf chain, so differences are summation-order only (1e-5 relative to the operand scale)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a = a.double().cpu()
+    b = b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def _nhwc(x):  # NCHW cpu -> NHWC cuda
+    return x.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def _nchw(x):  # NHWC cuda -> NCHW cpu
+    return x.permute(0, 3, 1, 2).cpu()
+
+
+def _ref_conv(x, w, b, kind):
+    if kind == "c3":
+        return F.conv2d(x, w, b, 1, 1)
+    if kind == "c1":
+        return F.conv2d(x, w, b)
+    if kind == "c3s2":
+        return F.conv2d(F.pad(x, (0, 1, 0, 1)), w, b, 2, 0)
+    if kind == "c3up":
+        return F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, b, 1, 1)
+
+
+def _to_dev_ohwi(w):
+    co, ci, kh, kw = w.shape
+    buf = w.permute(0, 2, 3, 1).contiguous().cuda()  # OHWI memory
+    return buf.permute(0, 3, 1, 2)  # logical OIHW view
+
+
+CONV_CASES = [
+    # kind, B, H, W, Ci, Co
+    ("c3", 2, 8, 8, 128, 128),
+    ("c3", 1, 12, 20, 128, 256),
+    ("c3", 2, 5, 7, 256, 128),      # ragged M
+    ("c3", 2, 16, 16, 3, 128),      # conv_in (scalar path)
+    ("c3", 2, 16, 16, 128, 3),      # conv_out (skinny N)
+    ("c3", 2, 4, 4, 512, 8),        # encoder.conv_out
+    ("c3", 2, 4, 4, 4, 512),        # decoder.conv_in
+    ("c1", 2, 8, 8, 128, 256),      # shortcut
+    ("c1", 2, 4, 4, 8, 8),          # quant_conv
+    ("c1", 2, 4, 4, 4, 4),          # post_quant_conv
+    ("c3s2", 2, 16, 16, 128, 128),  # downsampler
+    ("c3s2", 1, 10, 14, 128, 128),
+    ("c3up", 2, 8, 8, 128, 128),    # upsampler
+    ("c3up", 1, 5, 6, 256, 256),
+]
+
+
+@pytest.mark.parametrize("kind,B,H,W,Ci,Co", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(cuda, kind, B, H, W, Ci, Co):
+    from vaehip import ops
+    gen = torch.Generator().manual_seed(1234 + Ci + Co + H)
+    k = 1 if kind == "c1" else 3
+    x = torch.randn(B, Ci, H, W, generator=gen)
+    w = torch.randn(Co, Ci, k, k, generator=gen) / math.sqrt(Ci * k * k)
+    b = torch.randn(Co, generator=gen)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    y_ref = _ref_conv(xr, wr, br, kind)
+    dy = torch.randn(y_ref.shape, generator=gen)
+    y_ref.backward(dy)
+
+    cpad = 4 if Ci == 3 else Ci
+    xd = torch.zeros(B, H, W, cpad)
+    xd[..., :Ci] = x.permute(0, 2, 3, 1)
+    xd = xd.cuda()
+    wd = _to_dev_ohwi(w)
+    y = ops.conv_fwd(xd, wd, b.cuda(), kind)
+    assert _rel(_nchw(y), y_ref.detach()) < 2e-5
+
+    dyd = _nhwc(dy)
+    if Ci != 3:
+        dx = ops.conv_dgrad(dyd, wd, kind, (H, W))
+        assert _rel(_nchw(dx), xr.grad) < 2e-5
+    gw = torch.full_like(wd.permute(0, 2, 3, 1).contiguous(), float("nan")).permute(0, 3, 1, 2)
+    gb = torch.full((Co,), float("nan"), device="cuda")
+    ops.conv_wgrad(dyd, xd, kind, gw, gb)
+    assert _rel(gw.cpu(), wr.grad) < 3e-5
+    assert _rel(gb.cpu(), br.grad) < 3e-5
+
+
+@pytest.mark.parametrize("C,H,W,silu", [(128, 16, 16, True), (256, 8, 8, True), (512, 4, 4, True), (512, 6, 10, False)])
+def test_gn_fused_conv_and_backward(cuda, C, H, W, silu):
+    """GroupNorm(+SiLU) fused into the conv operand load; GN backward; tracker reduction."""
+    from vaehip import ops
+    gen = torch.Generator().manual_seed(7 + C)
+    B, Co = 2, 128
+    x = torch.randn(B, C, H, W, generator=gen) * 1.7 + 0.3
+    gamma = 1 + 0.3 * torch.randn(C, generator=gen)
+    beta = 0.2 * torch.randn(C, generator=gen)
+    w = torch.randn(Co, C, 3, 3, generator=gen) / math.sqrt(9 * C)
+    res = torch.randn(B, Co, H, W, generator=gen)
+    xr, gr, br, wr = (t.clone().requires_grad_(True) for t in (x, gamma, beta, w))
+    n = F.group_norm(xr, 32, gr, br, 1e-6)
+    act = F.silu(n) if silu else n
+    y_ref = F.conv2d(act, wr, None, 1, 1) + res
+    dy = torch.randn(y_ref.shape, generator=gen)
+    y_ref.backward(dy)
+
+    xd, gd, bd, wd = _nhwc(x), gamma.cuda(), beta.cuda(), _to_dev_ohwi(w)
+    st = ops.gn_stats(xd, gd, bd)
+    mean_ref = x.view(B, 32, -1).mean(-1)
+    var_ref = x.view(B, 32, -1).var(-1, unbiased=False)
+    assert _rel(st.mean, mean_ref) < 1e-5
+    assert _rel(st.rstd, 1 / torch.sqrt(var_ref + 1e-6)) < 1e-5
+    xf = ops.XF_AFFINE_SILU if silu else ops.XF_AFFINE
+    y = ops.conv_fwd(xd, wd, None, "c3", xf=xf, stats=st, res=_nhwc(res))
+    assert _rel(_nchw(y), y_ref.detach()) < 3e-5
+    # materialised GN output (hook slow path) and the fused tracker metric (monitor.py:66)
+    nd = ops.gn_apply(xd, st, ops.XF_AFFINE)
+    assert _rel(_nchw(nd), n.detach()) < 1e-5
+    tr = ops.gn_track(xd, st)
+    tr_ref = n.detach().abs().mean(dim=[0, 2, 3])
+    assert float(((tr.cpu() - tr_ref).abs() / tr_ref).max()) < 1e-5
+    # backward
+    dyd = _nhwc(dy)
+    gw = torch.empty_like(wd.permute(0, 2, 3, 1).contiguous()).permute(0, 3, 1, 2)
+    ops.conv_wgrad(dyd, xd, "c3", gw, None, xf=xf, stats=st)
+    assert _rel(gw.cpu(), wr.grad) < 5e-5
+    g = ops.conv_dgrad(dyd, wd, "c3", (H, W))
+    dgam = torch.empty(C, device="cuda")
+    dbet = torch.empty(C, device="cuda")
+    addt = torch.randn(B, H, W, C, generator=gen)
+    dx = ops.gn_bwd(xd, g, st, gd, bd, silu, addt.cuda(), dgam, dbet)
+    assert _rel(_nchw(dx) - addt.permute(0, 3, 1, 2), xr.grad) < 5e-5
+    assert _rel(dgam, gr.grad) < 5e-5
+    assert _rel(dbet, br.grad) < 5e-5
+
+
+def test_conv_track_epilogue(cuda):
+    from vaehip import ops
+    gen = torch.Generator().manual_seed(5)
+    B, H, W, Ci, Co = 2, 16, 16, 3, 128
+    x = torch.rand(B, Ci, H, W, generator=gen) * 2 - 1
+    w = torch.randn(Co, Ci, 3, 3, generator=gen) / math.sqrt(27)
+    b = torch.randn(Co, generator=gen) * 0.1
+    xd = torch.zeros(B, H, W, 4)
+    xd[..., :3] = x.permute(0, 2, 3, 1)
+    xd = xd.cuda()
+    ws = ops.conv_track_buffer(B * H * W, Co, "cuda")
+    y = ops.conv_fwd(xd, _to_dev_ohwi(w), b.cuda(), "c3", track=ws)
+    tr = ops.track_final(ws, B * H * W)
+    ref = F.conv2d(x, w, b, 1, 1).abs().mean(dim=[0, 2, 3])
+    assert float(((tr.cpu() - ref).abs() / ref).max()) < 1e-5
+
+
+@pytest.mark.parametrize("z,M,N,K", [(2, 64, 64, 512), (3, 100, 36, 40), (1, 256, 512, 256)])
+def test_batched_gemms(cuda, z, M, N, K):
+    from vaehip import ops
+    gen = torch.Generator().manual_seed(z * 100 + M)
+    A = torch.randn(z, M, K, generator=gen)
+    Bt = torch.randn(z, N, K, generator=gen)
+    assert _rel(ops.gemm_nt(A.cuda(), Bt.cuda(), 0.5), 0.5 * A @ Bt.transpose(1, 2)) < 2e-5
+    Bn = torch.randn(z, K, N, generator=gen)
+    assert _rel(ops.gemm_nn(A.cuda(), Bn.cuda()), A @ Bn) < 2e-5
+    At = torch.randn(z, K, M, generator=gen)
+    assert _rel(ops.gemm_tn(At.cuda(), Bn.cuda(), 2.0), 2.0 * At.transpose(1, 2) @ Bn) < 2e-5
+
+
+def test_softmax_fwd_bwd(cuda):
+    from vaehip import ops
+    gen = torch.Generator().manual_seed(3)
+    S = (torch.randn(2, 70, 300, generator=gen) * 3).requires_grad_(True)
+    P_ref = torch.softmax(S, -1)
+    dP = torch.randn(P_ref.shape, generator=gen)
+    P_ref.backward(dP)
+    P = ops.softmax_rows_(S.detach().clone().cuda())
+    assert _rel(P, P_ref.detach()) < 1e-5
+    dS = ops.softmax_bwd_rows_(P, dP.clone().cuda())
+    assert _rel(dS, S.grad) < 2e-5
+
+
+def test_sample_kl_mse_and_backward(cuda):
+    from vaehip import ops
+    gen = torch.Generator().manual_seed(11)
+    B, h, w, L, R = 3, 4, 4, 4, 32
+    mom = torch.randn(B, 2 * L, h, w, generator=gen) * 2
+    mom[0, L, 0, 0] = 25.0   # exercises clamp(max=20): zero gradient
+    mom[1, L + 1, 1, 1] = -40.0
+    eps = torch.randn(B, L, h, w, generator=gen)
+    target = torch.rand(B, 3, R, R, generator=gen) * 2 - 1
+    recon = torch.randn(B, 3, R, R, generator=gen)
+    klw = 1e-3
+    mr = mom.clone().requires_grad_(True)
+    rr = recon.clone().requires_grad_(True)
+    mean, lv = torch.chunk(mr, 2, 1)
+    lvc = lv.clamp(-30, 20)
+    z_ref = mean + torch.exp(0.5 * lvc) * eps
+    kl = 0.5 * torch.sum(mean ** 2 + lvc.exp() - 1 - lvc, dim=[1, 2, 3])
+    mse = F.mse_loss(rr, target)
+    dz = torch.randn(z_ref.shape, generator=gen)
+    total = mse + klw * kl.mean() + (z_ref * dz).sum()
+    total.backward()
+
+    md, ed = _nhwc(mom), _nhwc(eps)
+    z, klp = ops.sample_kl(md, ed)
+    assert _rel(_nchw(z), z_ref.detach()) < 1e-6
+    assert _rel(klp.sum(1), kl.detach()) < 1e-5
+    rd, td = _nhwc(recon), _nhwc(target)
+    sc = ops.mse_kl_loss(rd, td, klp, klw).cpu()
+    assert abs(sc[0] - mse.item()) / mse.item() < 1e-6
+    assert abs(sc[1] - kl.mean().item()) / abs(kl.mean().item()) < 1e-5
+    assert abs(sc[2] - (mse + klw * kl.mean()).item()) < 1e-5
+    assert _rel(_nchw(ops.mse_bwd(rd, td)), rr.grad) < 1e-6
+    dm = ops.sample_kl_bwd(md, ed, _nhwc(dz), klw)
+    assert _rel(_nchw(dm), mr.grad) < 1e-5
+    # mode(): eps None
+    z0, _ = ops.sample_kl(md, None)
+    assert _rel(_nchw(z0), mom[:, :L]) == 0.0
+
+
+def test_layout_and_pool(cuda):
+    from vaehip import ops
+    gen = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 3, 6, 10, generator=gen)
+    y = ops.nchw_to_nhwc(x.cuda(), 4).cpu()
+    assert torch.equal(y[..., :3], x.permute(0, 2, 3, 1)) and float(y[..., 3].abs().max()) == 0.0
+    assert torch.equal(ops.nhwc_to_nchw(ops.nchw_to_nhwc(x.cuda())).cpu(), x)
+    s = torch.randn(2, 8, 12, 128, generator=gen)
+    from vaehip.lib import lib
+    out = torch.empty(2, 4, 6, 128, device="cuda")
+    lib.call("vae_sumpool2x2", ops._p(s.cuda()), 2, 4, 6, 128, ops._p(out), ops._stream())
+    ref = s.view(2, 4, 2, 6, 2, 128).sum(dim=(2, 4))
+    assert _rel(out, ref) < 1e-6
+
+
+def test_fused_clip_adamw_matches_torch(cuda):
+    """train.py:184-187,301-302: clip_grad_norm_(1.0) then torch.optim.AdamW, 3 steps incl. lr=0 first step."""
+    from vaehip import ops
+    gen = torch.Generator().manual_seed(21)
+    n = 100003
+    p0 = torch.randn(n, generator=gen)
+    p_ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([p_ref], lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8)
+    p = p0.clone().cuda()
+    m = torch.zeros(n, device="cuda")
+    v = torch.zeros(n, device="cuda")
+    sq = torch.zeros(1, device="cuda")
+    for step, lr in enumerate([0.0, 1e-3, 5e-4], start=1):
+        g = torch.randn(n, generator=gen) * (3.0 if step != 2 else 1e-3)
+        p_ref.grad = g.clone()
+        tn = torch.nn.utils.clip_grad_norm_([p_ref], 1.0)
+        for grp in opt.param_groups:
+            grp["lr"] = lr
+        opt.step()
+        gd = g.cuda()
+        ops.sqnorm(gd, sq)
+        assert abs(math.sqrt(sq.item()) - tn.item()) / tn.item() < 1e-5
+        ops.adamw(p, gd, m, v, sq, 1.0, lr, 0.9, 0.999, 1e-8, 1e-2, step)
+        assert _rel(p, p_ref.detach()) < 1e-6
+    st = opt.state[p_ref]
+    # v carries clip^2: twice the fp32 summation-order difference of the two norm computations
+    assert _rel(m, st["exp_avg"]) < 1e-5 and _rel(v, st["exp_avg_sq"]) < 5e-5
+
+
+def test_errors_are_loud(cuda):
+    from vaehip import ops, VaeHipError
+    x = torch.zeros(1, 4, 4, 128, device="cuda")
+    w = torch.zeros(128, 128, 3, 3, device="cuda")  # NOT channels_last memory
+    with pytest.raises(ValueError):
+        ops.conv_fwd(x, w, None, "c3")
+    from vaehip.lib import lib
+    with pytest.raises(VaeHipError):
+        lib.call("vae_add", None, None, 0, None, None)

@@ -1,0 +1,392 @@
+// GroupNorm(32 groups) statistics, tracker reduction and backward for NHWC fp32.
+// All kernels are HBM-bound streaming passes: lanes run across channels (float4 per lane,
+// fully coalesced rows), each workgroup owns one pixel chunk of one image, and every
+// cross-workgroup reduction is "per-workgroup partial + fixed-order final pass" so results
+// are bitwise reproducible (the inactivity mask of classifier.py:135 depends on it).
+#include "common.h"
+
+namespace {
+
+// layout helper: 256 threads = PR pixel rows x Q float4 lanes (Q = C/4)
+struct Lay {
+  int Q, PR, cq, pr;
+};
+__device__ __forceinline__ Lay make_lay(int C) {
+  Lay l;
+  l.Q = C >> 2;
+  l.PR = 256 / l.Q;
+  l.cq = threadIdx.x % l.Q;
+  l.pr = threadIdx.x / l.Q;
+  return l;
+}
+
+__global__ __launch_bounds__(256) void gn_stats_partial_kernel(const float* __restrict__ x, int HW, int C, int G,
+                                                               int nchunk, float* __restrict__ ws) {
+  __shared__ float red[2][256];
+  const Lay l = make_lay(C);
+  const int chunk = blockIdx.x, b = blockIdx.y;
+  const int per = (HW + nchunk - 1) / nchunk;
+  const int p0 = chunk * per, p1 = min(HW, p0 + per);
+  const float* xb = x + (int64_t)b * HW * C;
+  f32x4 s = {0, 0, 0, 0}, q = {0, 0, 0, 0};
+  for (int pix = p0 + l.pr; pix < p1; pix += l.PR) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(xb + (int64_t)pix * C + l.cq * 4);
+    s += v;
+    q += v * v;
+  }
+  red[0][threadIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
+  red[1][threadIdx.x] = (q[0] + q[1]) + (q[2] + q[3]);
+  __syncthreads();
+  if (threadIdx.x < G) {
+    const int g = threadIdx.x;
+    const int lanes = (C / G) >> 2;  // float4 lanes per group
+    float ts = 0.f, tq = 0.f;
+    for (int pr = 0; pr < l.PR; ++pr)
+      for (int j = 0; j < lanes; ++j) {
+        int t = pr * l.Q + g * lanes + j;
+        ts += red[0][t];
+        tq += red[1][t];
+      }
+    float* o = ws + (((int64_t)b * nchunk + chunk) * G + g) * 2;
+    o[0] = ts;
+    o[1] = tq;
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_stats_final_kernel(const float* __restrict__ ws, int HW, int C, int G,
+                                                             int nchunk, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps,
+                                                             float* __restrict__ mean, float* __restrict__ rstd,
+                                                             float* __restrict__ scale, float* __restrict__ shift) {
+  __shared__ float smean[64], srstd[64];
+  const int b = blockIdx.x;
+  if (threadIdx.x < G) {
+    const int g = threadIdx.x;
+    double S = 0.0, Q = 0.0;
+    for (int c = 0; c < nchunk; ++c) {
+      const float* o = ws + (((int64_t)b * nchunk + c) * G + g) * 2;
+      S += (double)o[0];
+      Q += (double)o[1];
+    }
+    const double n = (double)HW * (double)(C / G);
+    const double m = S / n;
+    double var = Q / n - m * m;
+    if (var < 0.0) var = 0.0;
+    const float mf = (float)m, rf = (float)(1.0 / sqrt(var + (double)eps));
+    smean[g] = mf;
+    srstd[g] = rf;
+    mean[b * G + g] = mf;
+    rstd[b * G + g] = rf;
+  }
+  __syncthreads();
+  const int cpg = C / G;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int g = c / cpg;
+    const float sc = srstd[g] * gamma[c];
+    scale[(int64_t)b * C + c] = sc;
+    shift[(int64_t)b * C + c] = beta[c] - smean[g] * sc;
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, int64_t n4, int HWQ, int Q,
+                                                       int C, int xf, float* __restrict__ y) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (; i < n4; i += stride) {
+    const int b = (int)(i / HWQ);
+    const int c = (int)(i % Q) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+    f32x4 sc = *reinterpret_cast<const f32x4*>(scale + (int64_t)b * C + c);
+    f32x4 sh = *reinterpret_cast<const f32x4*>(shift + (int64_t)b * C + c);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float u = v[e] * sc[e] + sh[e];
+      o[e] = (xf == VAE_XF_AFFINE_SILU) ? silu_f(u) : u;
+    }
+    *reinterpret_cast<f32x4*>(y + i * 4) = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_track_partial_kernel(const float* __restrict__ x,
+                                                               const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, int HW, int C,
+                                                               int nchunk, float* __restrict__ ws) {
+  __shared__ f32x4 red[256];
+  const Lay l = make_lay(C);
+  const int chunk = blockIdx.x, b = blockIdx.y;
+  const int per = (HW + nchunk - 1) / nchunk;
+  const int p0 = chunk * per, p1 = min(HW, p0 + per);
+  const float* xb = x + (int64_t)b * HW * C;
+  const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + (int64_t)b * C + l.cq * 4);
+  const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + (int64_t)b * C + l.cq * 4);
+  f32x4 s = {0, 0, 0, 0};
+  for (int pix = p0 + l.pr; pix < p1; pix += l.PR) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(xb + (int64_t)pix * C + l.cq * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[e] += fabsf(v[e] * sc[e] + sh[e]);
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < l.Q) {
+    f32x4 t = {0, 0, 0, 0};
+    for (int pr = 0; pr < l.PR; ++pr) t += red[pr * l.Q + threadIdx.x];
+    *reinterpret_cast<f32x4*>(ws + ((int64_t)b * nchunk + chunk) * C + threadIdx.x * 4) = t;
+  }
+}
+
+__global__ __launch_bounds__(256) void track_final_kernel(const float* __restrict__ ws, int rows, int C,
+                                                          float inv_count, float* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int r = 0; r < rows; ++r) s += (double)ws[(int64_t)r * C + c];
+  out[c] = (float)(s * (double)inv_count);
+}
+
+template <bool SILU>
+__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, int HW, int C, int G,
+                                                             int nchunk, float* __restrict__ ws) {
+  __shared__ f32x4 red[2][256];
+  const Lay l = make_lay(C);
+  const int chunk = blockIdx.x, b = blockIdx.y;
+  const int per = (HW + nchunk - 1) / nchunk;
+  const int p0 = chunk * per, p1 = min(HW, p0 + per);
+  const int c = l.cq * 4, grp = c / (C / G);
+  const float mu = mean[b * G + grp], rs = rstd[b * G + grp];
+  const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
+  const f32x4 be = *reinterpret_cast<const f32x4*>(beta + c);
+  const float* xb = x + (int64_t)b * HW * C;
+  const float* gb = g + (int64_t)b * HW * C;
+  f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+  for (int pix = p0 + l.pr; pix < p1; pix += l.PR) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(xb + (int64_t)pix * C + c);
+    f32x4 gv = *reinterpret_cast<const f32x4*>(gb + (int64_t)pix * C + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float xh = (v[e] - mu) * rs;
+      float du = gv[e];
+      if (SILU) du *= silu_grad_f(xh * ga[e] + be[e]);
+      s1[e] += du;
+      s2[e] += du * xh;
+    }
+  }
+  red[0][threadIdx.x] = s1;
+  red[1][threadIdx.x] = s2;
+  __syncthreads();
+  if (threadIdx.x < l.Q) {
+    f32x4 t1 = {0, 0, 0, 0}, t2 = {0, 0, 0, 0};
+    for (int pr = 0; pr < l.PR; ++pr) {
+      t1 += red[0][pr * l.Q + threadIdx.x];
+      t2 += red[1][pr * l.Q + threadIdx.x];
+    }
+    float* o = ws + (((int64_t)b * nchunk + chunk) * C + threadIdx.x * 4) * 2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o[e * 2 + 0] = t1[e];
+      o[e * 2 + 1] = t2[e];
+    }
+  }
+}
+
+// blocks 0..B-1: coef for batch b; block B: dgamma/dbeta
+__global__ __launch_bounds__(256) void gn_bwd_final_kernel(const float* __restrict__ ws, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, int B, int HW, int C,
+                                                           int G, int nchunk, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, float* __restrict__ coef) {
+  __shared__ float sg1[512], sg2[512];
+  const int cpg = C / G;
+  if ((int)blockIdx.x < B) {
+    const int b = blockIdx.x;
+    for (int c0 = 0; c0 < C; c0 += 512) {  // C <= 512 in practice; loop keeps it general
+      __syncthreads();
+      for (int c = c0 + threadIdx.x; c < min(C, c0 + 512); c += 256) {
+        double a1 = 0.0, a2 = 0.0;
+        for (int k = 0; k < nchunk; ++k) {
+          const float* o = ws + (((int64_t)b * nchunk + k) * C + c) * 2;
+          a1 += (double)o[0];
+          a2 += (double)o[1];
+        }
+        sg1[c - c0] = (float)(a1 * (double)gamma[c]);
+        sg2[c - c0] = (float)(a2 * (double)gamma[c]);
+      }
+      __syncthreads();
+      const int g0 = c0 / cpg, g1 = min(C, c0 + 512) / cpg;
+      for (int g = g0 + threadIdx.x; g < g1; g += 256) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int j = 0; j < cpg; ++j) {
+          s1 += (double)sg1[g * cpg + j - c0];
+          s2 += (double)sg2[g * cpg + j - c0];
+        }
+        const double n = (double)HW * (double)cpg;
+        const double r = (double)rstd[b * G + g];
+        coef[((int64_t)b * G + g) * 2 + 0] = (float)(r * s2 / n);
+        coef[((int64_t)b * G + g) * 2 + 1] = (float)(r * s1 / n);
+      }
+    }
+  } else {
+    for (int c = threadIdx.x; c < C; c += 256) {
+      double a1 = 0.0, a2 = 0.0;
+      for (int r = 0; r < B * nchunk; ++r) {
+        const float* o = ws + ((int64_t)r * C + c) * 2;
+        a1 += (double)o[0];
+        a2 += (double)o[1];
+      }
+      dbeta[c] = (float)a1;
+      dgamma[c] = (float)a2;
+    }
+  }
+}
+
+template <bool SILU>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta,
+                                                           const float* __restrict__ coef,
+                                                           const float* __restrict__ add, int64_t n4, int HWQ, int Q,
+                                                           int C, int G, float* __restrict__ dx) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const int cpg = C / G;
+  for (; i < n4; i += stride) {
+    const int b = (int)(i / HWQ);
+    const int c = (int)(i % Q) * 4;
+    const int grp = c / cpg;
+    const float mu = mean[b * G + grp], rs = rstd[b * G + grp];
+    const float k0 = coef[((int64_t)b * G + grp) * 2 + 0], k1 = coef[((int64_t)b * G + grp) * 2 + 1];
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+    f32x4 gv = *reinterpret_cast<const f32x4*>(g + i * 4);
+    f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
+    f32x4 be = *reinterpret_cast<const f32x4*>(beta + c);
+    f32x4 o;
+    if (add) o = *reinterpret_cast<const f32x4*>(add + i * 4);
+    else o = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float xh = (v[e] - mu) * rs;
+      float du = gv[e];
+      if (SILU) du *= silu_grad_f(xh * ga[e] + be[e]);
+      o[e] += du * (rs * ga[e]) - xh * k0 - k1;
+    }
+    *reinterpret_cast<f32x4*>(dx + i * 4) = o;
+  }
+}
+
+int check_gn(const char* who, int B, int HW, int C, int G, int nchunk) {
+  VAE_CHECK(B > 0 && HW > 0 && C > 0 && G > 0 && nchunk > 0, "%s: non-positive size", who);
+  VAE_CHECK(C % 4 == 0 && (C / 4) <= 256 && 256 % (C / 4) == 0, "%s: C=%d must be 4*{1,2,4,...,256}", who, C);
+  VAE_CHECK(C % G == 0 && (C / G) % 4 == 0, "%s: channels per group must be a multiple of 4 (C=%d G=%d)", who, C, G);
+  VAE_CHECK(G <= 64, "%s: G=%d > 64", who, G);
+  VAE_CHECK(nchunk <= 65535 && B <= 65535, "%s: grid too large", who);
+  return 0;
+}
+inline int ew_blocks(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+extern "C" int vae_gn_stats_partial(const float* x, int32_t B, int32_t HW, int32_t C, int32_t G, int32_t nchunk,
+                                    float* ws, void* stream) {
+  if (int e = check_gn("gn_stats_partial", B, HW, C, G, nchunk)) return e;
+  VAE_CHECK(x && ws && aligned16(x), "gn_stats_partial: bad pointers");
+  hipLaunchKernelGGL(gn_stats_partial_kernel, dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream, x, HW, C, G, nchunk, ws);
+  VAE_LAUNCH_CHECK("gn_stats_partial");
+  return VAE_OK;
+}
+
+extern "C" int vae_gn_stats_final(const float* ws, int32_t B, int32_t HW, int32_t C, int32_t G, int32_t nchunk,
+                                  const float* gamma, const float* beta, float eps, float* mean, float* rstd,
+                                  float* scale, float* shift, void* stream) {
+  if (int e = check_gn("gn_stats_final", B, HW, C, G, nchunk)) return e;
+  VAE_CHECK(ws && gamma && beta && mean && rstd && scale && shift, "gn_stats_final: null pointer");
+  hipLaunchKernelGGL(gn_stats_final_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, ws, HW, C, G, nchunk, gamma, beta,
+                     eps, mean, rstd, scale, shift);
+  VAE_LAUNCH_CHECK("gn_stats_final");
+  return VAE_OK;
+}
+
+extern "C" int vae_gn_apply(const float* x, const float* scale, const float* shift, int32_t B, int32_t HW, int32_t C,
+                            int32_t xf, float* y, void* stream) {
+  VAE_CHECK(x && scale && shift && y && B > 0 && HW > 0 && C > 0 && C % 4 == 0, "gn_apply: bad args");
+  VAE_CHECK(aligned16(x) && aligned16(y) && aligned16(scale) && aligned16(shift), "gn_apply: unaligned");
+  const int Q = C / 4;
+  const int64_t n4 = (int64_t)B * HW * Q;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, n4, HW * Q, Q,
+                     C, xf, y);
+  VAE_LAUNCH_CHECK("gn_apply");
+  return VAE_OK;
+}
+
+extern "C" int vae_gn_track_partial(const float* x, const float* scale, const float* shift, int32_t B, int32_t HW,
+                                    int32_t C, int32_t nchunk, float* ws, void* stream) {
+  VAE_CHECK(B > 0 && HW > 0 && nchunk > 0 && nchunk <= 65535 && B <= 65535, "gn_track_partial: bad sizes");
+  VAE_CHECK(C > 0 && C % 4 == 0 && (C / 4) <= 256 && 256 % (C / 4) == 0, "gn_track_partial: C=%d unsupported", C);
+  VAE_CHECK(x && scale && shift && ws && aligned16(x) && aligned16(scale) && aligned16(shift) && aligned16(ws),
+            "gn_track_partial: bad pointers");
+  hipLaunchKernelGGL(gn_track_partial_kernel, dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream, x, scale, shift, HW, C,
+                     nchunk, ws);
+  VAE_LAUNCH_CHECK("gn_track_partial");
+  return VAE_OK;
+}
+
+extern "C" int vae_track_final(const float* ws, int32_t rows, int32_t C, float inv_count, float* out, void* stream) {
+  VAE_CHECK(ws && out && rows > 0 && C > 0, "track_final: bad args");
+  hipLaunchKernelGGL(track_final_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, rows, C, inv_count, out);
+  VAE_LAUNCH_CHECK("track_final");
+  return VAE_OK;
+}
+
+extern "C" int vae_gn_bwd_partial(const float* x, const float* g, const float* mean, const float* rstd,
+                                  const float* gamma, const float* beta, int32_t B, int32_t HW, int32_t C, int32_t G,
+                                  int32_t nchunk, int32_t silu, float* ws, void* stream) {
+  if (int e = check_gn("gn_bwd_partial", B, HW, C, G, nchunk)) return e;
+  VAE_CHECK(x && g && mean && rstd && gamma && beta && ws, "gn_bwd_partial: null pointer");
+  VAE_CHECK(aligned16(x) && aligned16(g) && aligned16(gamma) && aligned16(beta), "gn_bwd_partial: unaligned");
+  if (silu)
+    hipLaunchKernelGGL(gn_bwd_partial_kernel<true>, dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream, x, g, mean, rstd,
+                       gamma, beta, HW, C, G, nchunk, ws);
+  else
+    hipLaunchKernelGGL(gn_bwd_partial_kernel<false>, dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream, x, g, mean, rstd,
+                       gamma, beta, HW, C, G, nchunk, ws);
+  VAE_LAUNCH_CHECK("gn_bwd_partial");
+  return VAE_OK;
+}
+
+extern "C" int vae_gn_bwd_final(const float* ws, const float* rstd, const float* gamma, int32_t B, int32_t HW, int32_t C,
+                                int32_t G, int32_t nchunk, float* dgamma, float* dbeta, float* coef, void* stream) {
+  if (int e = check_gn("gn_bwd_final", B, HW, C, G, nchunk)) return e;
+  VAE_CHECK(ws && rstd && gamma && dgamma && dbeta && coef, "gn_bwd_final: null pointer");
+  hipLaunchKernelGGL(gn_bwd_final_kernel, dim3(B + 1), dim3(256), 0, (hipStream_t)stream, ws, rstd, gamma, B, HW, C, G,
+                     nchunk, dgamma, dbeta, coef);
+  VAE_LAUNCH_CHECK("gn_bwd_final");
+  return VAE_OK;
+}
+
+extern "C" int vae_gn_bwd_apply(const float* x, const float* g, const float* mean, const float* rstd,
+                                const float* gamma, const float* beta, const float* coef, const float* add, int32_t B,
+                                int32_t HW, int32_t C, int32_t G, int32_t silu, float* dx, void* stream) {
+  if (int e = check_gn("gn_bwd_apply", B, HW, C, G, 1)) return e;
+  VAE_CHECK(x && g && mean && rstd && gamma && beta && coef && dx, "gn_bwd_apply: null pointer");
+  VAE_CHECK(aligned16(x) && aligned16(g) && aligned16(dx) && aligned16(gamma) && aligned16(beta) &&
+                (add == nullptr || aligned16(add)),
+            "gn_bwd_apply: unaligned");
+  const int Q = C / 4;
+  const int64_t n4 = (int64_t)B * HW * Q;
+  if (silu)
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, x, g, mean, rstd,
+                       gamma, beta, coef, add, n4, HW * Q, Q, C, G, dx);
+  else
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, x, g, mean, rstd,
+                       gamma, beta, coef, add, n4, HW * Q, Q, C, G, dx);
+  VAE_LAUNCH_CHECK("gn_bwd_apply");
+  return VAE_OK;
+}

@@ -1,0 +1,106 @@
+"""ctypes loader for libvaehip.so (C ABI declared in include/vaehip.h)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "csrc", "libvaehip.so"))
+
+
+class VaeHipError(RuntimeError):
+    pass
+
+
+class ConvGeom(C.Structure):
+    _fields_ = [("B", C.c_int32), ("Hs", C.c_int32), ("Ws", C.c_int32), ("Cs", C.c_int32),
+                ("Ho", C.c_int32), ("Wo", C.c_int32), ("taps", C.c_int32), ("stride", C.c_int32),
+                ("pad_t", C.c_int32), ("pad_l", C.c_int32), ("mode", C.c_int32)]
+
+
+_fp = C.c_void_p
+
+
+class IgemmArgs(C.Structure):
+    _fields_ = [("A", _fp), ("W", _fp), ("C", _fp), ("bias", _fp), ("res", _fp), ("scale", _fp), ("shift", _fp),
+                ("track", _fp), ("g", ConvGeom), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+                ("ldc", C.c_int32), ("sn", C.c_int64), ("sk", C.c_int64), ("st", C.c_int64),
+                ("batch", C.c_int32), ("sAb", C.c_int64), ("sWb", C.c_int64), ("sCb", C.c_int64),
+                ("xf", C.c_int32), ("alpha", C.c_float)]
+
+
+class WgradArgs(C.Structure):
+    _fields_ = [("dY", _fp), ("X", _fp), ("out", _fp), ("partial", _fp), ("scale", _fp), ("shift", _fp),
+                ("g", ConvGeom), ("M", C.c_int32), ("N", C.c_int32), ("ldy", C.c_int32), ("npix", C.c_int32),
+                ("nsplit", C.c_int32), ("batch", C.c_int32), ("sYb", C.c_int64), ("sXb", C.c_int64),
+                ("sOb", C.c_int64), ("xf", C.c_int32), ("alpha", C.c_float)]
+
+
+i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+# name -> argtypes (every function returns int); must list EVERY symbol of include/vaehip.h
+SIGNATURES = {
+    "vae_igemm_rows": [C.POINTER(IgemmArgs), vp],
+    "vae_wgrad": [C.POINTER(WgradArgs), vp],
+    "vae_reduce_splits": [vp, i32, i64, vp, vp],
+    "vae_colsum": [vp, i64, i32, vp, vp, vp],
+    "vae_gn_stats_partial": [vp, i32, i32, i32, i32, i32, vp, vp],
+    "vae_gn_stats_final": [vp, i32, i32, i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp],
+    "vae_gn_apply": [vp, vp, vp, i32, i32, i32, i32, vp, vp],
+    "vae_gn_track_partial": [vp, vp, vp, i32, i32, i32, i32, vp, vp],
+    "vae_track_final": [vp, i32, i32, f32, vp, vp],
+    "vae_gn_bwd_partial": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp],
+    "vae_gn_bwd_final": [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp],
+    "vae_gn_bwd_apply": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp],
+    "vae_softmax_rows": [vp, i64, i32, vp],
+    "vae_softmax_bwd_rows": [vp, vp, i64, i32, vp],
+    "vae_sample_kl": [vp, vp, i32, i32, i32, vp, vp, vp],
+    "vae_mse_partial": [vp, vp, i64, vp, i32, vp],
+    "vae_loss_final": [vp, i32, i64, vp, i32, i32, f32, vp, vp],
+    "vae_mse_bwd": [vp, vp, i64, vp, vp],
+    "vae_sample_kl_bwd": [vp, vp, vp, i32, i32, i32, f32, vp, vp],
+    "vae_nchw_to_nhwc": [vp, i32, i32, i32, i32, vp, vp],
+    "vae_nhwc_to_nchw": [vp, i32, i32, i32, vp, vp],
+    "vae_sumpool2x2": [vp, i32, i32, i32, i32, vp, vp],
+    "vae_add": [vp, vp, i64, vp, vp],
+    "vae_sqnorm": [vp, i64, vp, i32, vp, vp],
+    "vae_adamw": [vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, f32, i32, vp],
+    "vae_dead_scan": [vp, vp, i32, f32, vp, vp, vp],
+    "vae_dead_scan_adaptive": [vp, vp, i32, f32, i32, vp, vp, vp],
+}
+
+
+class _Lib:
+    """lazy loader; attribute access returns a checked wrapper around the C symbol."""
+
+    def __init__(self):
+        self._dll = None
+
+    def load(self):
+        if self._dll is None:
+            if not os.path.exists(LIB_PATH):
+                raise VaeHipError(
+                    f"libvaehip.so not found at {LIB_PATH}; build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    f"(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+            dll = C.CDLL(LIB_PATH)
+            dll.vae_last_error.restype = C.c_char_p
+            dll.vae_last_error.argtypes = []
+            dll.vae_abi_version.restype = C.c_int
+            for name, argt in SIGNATURES.items():
+                fn = getattr(dll, name)
+                fn.restype = C.c_int
+                fn.argtypes = argt
+            self._dll = dll
+        return self._dll
+
+    def call(self, name, *args):
+        dll = self.load()
+        rc = getattr(dll, name)(*args)
+        if rc != 0:
+            raise VaeHipError(f"{name} failed ({rc}): {dll.vae_last_error().decode()}")
+
+    def abi_version(self) -> int:
+        return self.load().vae_abi_version()
+
+
+lib = _Lib()

@@ -1,0 +1,399 @@
+"""Tensor-level wrappers over the C ABI.  Activations are NHWC fp32 CUDA tensors.
+
+Every function enqueues on torch's current HIP stream and never synchronises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple, Optional, Tuple
+
+import torch
+
+from .lib import ConvGeom, IgemmArgs, WgradArgs, lib
+
+XF_NONE, XF_AFFINE, XF_AFFINE_SILU = 0, 1, 2
+MODE_FWD, MODE_UP2X, MODE_DGRAD = 0, 1, 2
+GN_GROUPS = 32
+GN_EPS = 1e-6
+
+
+def _p(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t: torch.Tensor, name: str):
+    if not (t.is_cuda and t.dtype == torch.float32):
+        raise ValueError(f"{name}: expected a float32 CUDA tensor, got {t.dtype} on {t.device}")
+
+
+def _chk_c(t: torch.Tensor, name: str):
+    _chk(t, name)
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous NHWC tensor, strides {t.stride()}")
+
+
+def ohwi(w: torch.Tensor) -> torch.Tensor:
+    """nn.Conv2d weight (logical OIHW, channels_last memory) -> [O,KH,KW,I] contiguous view; nn.Linear -> [O,1,1,I]."""
+    if w.ndim == 2:
+        v = w.view(w.shape[0], 1, 1, w.shape[1])
+    else:
+        v = w.permute(0, 2, 3, 1)
+    if not v.is_contiguous():
+        raise ValueError("weight memory is not OHWI (channels_last); parameters must live in the VAE arena")
+    return v
+
+
+class Stats(NamedTuple):
+    mean: torch.Tensor   # [B, G]
+    rstd: torch.Tensor   # [B, G]
+    scale: torch.Tensor  # [B, C]
+    shift: torch.Tensor  # [B, C]
+
+
+# ------------------------------------------------------------------ conv geometry
+def out_hw(kind: str, H: int, W: int) -> Tuple[int, int]:
+    if kind in ("c3", "c1"):
+        return H, W
+    if kind == "c3s2":
+        return (H + 1 - 3) // 2 + 1, (W + 1 - 3) // 2 + 1
+    if kind == "c3up":
+        return 2 * H, 2 * W
+    raise ValueError(kind)
+
+
+def _fwd_geom(kind: str, B: int, H: int, W: int, Cs: int) -> ConvGeom:
+    Ho, Wo = out_hw(kind, H, W)
+    if kind == "c3":
+        return ConvGeom(B, H, W, Cs, Ho, Wo, 9, 1, 1, 1, MODE_FWD)
+    if kind == "c1":
+        return ConvGeom(B, H, W, Cs, Ho, Wo, 1, 1, 0, 0, MODE_FWD)
+    if kind == "c3s2":
+        return ConvGeom(B, H, W, Cs, Ho, Wo, 9, 2, 0, 0, MODE_FWD)
+    if kind == "c3up":
+        return ConvGeom(B, H, W, Cs, Ho, Wo, 9, 1, 1, 1, MODE_UP2X)
+    raise ValueError(kind)
+
+
+def conv_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], kind: str, *,
+             xf: int = XF_NONE, stats: Optional[Stats] = None, res: Optional[torch.Tensor] = None,
+             track: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [B,H,W,Cs] (Cs >= Cin, extra channels must be zero-weighted i.e. Cin is taken from w)."""
+    _chk_c(x, "conv_fwd.x")
+    wv = ohwi(w)
+    Co, kh, kw, Ci = wv.shape
+    B, H, W, Cs = x.shape
+    taps = kh * kw
+    assert taps == (1 if kind == "c1" else 9) and Ci <= Cs, (kind, wv.shape, x.shape)
+    g = _fwd_geom(kind, B, H, W, Cs)
+    out = torch.empty((B, g.Ho, g.Wo, Co), device=x.device, dtype=torch.float32)
+    if res is not None:
+        _chk_c(res, "conv_fwd.res")
+        assert res.shape == out.shape
+    a = IgemmArgs()
+    a.A, a.W, a.C, a.bias, a.res = _p(x), _p(wv), _p(out), _p(bias), _p(res)
+    if xf != XF_NONE:
+        assert stats is not None and stats.scale.shape == (B, Cs)
+        a.scale, a.shift = _p(stats.scale), _p(stats.shift)
+    a.track = _p(track)
+    a.g = g
+    a.M, a.N, a.K, a.ldc = B * g.Ho * g.Wo, Co, Ci, Co
+    a.sn, a.sk, a.st = taps * Ci, 1, Ci
+    a.batch, a.sAb, a.sWb, a.sCb = 1, 0, 0, 0
+    a.xf, a.alpha = xf, 1.0
+    if track is not None:
+        assert track.numel() >= ((a.M + 127) // 128) * Co
+    lib.call("vae_igemm_rows", C.byref(a), _stream())
+    return out
+
+
+def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, kind: str, in_hw: Tuple[int, int]) -> torch.Tensor:
+    """gradient wrt the conv input (the XF'ed tensor); dy [B,Ho,Wo,Co] -> [B,H,W,Ci]."""
+    _chk_c(dy, "conv_dgrad.dy")
+    wv = ohwi(w)
+    Co, kh, kw, Ci = wv.shape
+    taps = kh * kw
+    B, Hy, Wy, Cy = dy.shape
+    assert Cy == Co
+    H, W = in_hw
+    if kind == "c3up":
+        Hr, Wr, stride, pad = 2 * H, 2 * W, 1, 1
+    elif kind == "c3s2":
+        Hr, Wr, stride, pad = H, W, 2, 0
+    elif kind == "c3":
+        Hr, Wr, stride, pad = H, W, 1, 1
+    else:
+        Hr, Wr, stride, pad = H, W, 1, 0
+    g = ConvGeom(B, Hy, Wy, Co, Hr, Wr, taps, stride, pad, pad, MODE_DGRAD)
+    out = torch.empty((B, Hr, Wr, Ci), device=dy.device, dtype=torch.float32)
+    a = IgemmArgs()
+    a.A, a.W, a.C = _p(dy), _p(wv), _p(out)
+    a.g = g
+    a.M, a.N, a.K, a.ldc = B * Hr * Wr, Ci, Co, Ci
+    a.sn, a.sk, a.st = 1, taps * Ci, Ci
+    a.batch, a.sAb, a.sWb, a.sCb = 1, 0, 0, 0
+    a.xf, a.alpha = XF_NONE, 1.0
+    lib.call("vae_igemm_rows", C.byref(a), _stream())
+    if kind == "c3up":
+        pooled = torch.empty((B, H, W, Ci), device=dy.device, dtype=torch.float32)
+        lib.call("vae_sumpool2x2", _p(out), B, H, W, Ci, _p(pooled), _stream())
+        return pooled
+    return out
+
+
+def _nsplit(tiles: int, npix: int) -> int:
+    return max(1, min(1024 // max(tiles, 1), npix // 256))
+
+
+def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, kind: str, wgrad_out: torch.Tensor,
+               bgrad_out: Optional[torch.Tensor], *, xf: int = XF_NONE, stats: Optional[Stats] = None):
+    """writes dW into `wgrad_out` (a view with the weight's OHWI memory) and db into `bgrad_out`."""
+    _chk_c(dy, "conv_wgrad.dy")
+    _chk_c(x, "conv_wgrad.x")
+    gv = ohwi(wgrad_out)
+    Co, kh, kw, Ci = gv.shape
+    taps = kh * kw
+    B, H, W, Cs = x.shape
+    g = _fwd_geom(kind, B, H, W, Cs)
+    assert dy.shape == (B, g.Ho, g.Wo, Co), (dy.shape, (B, g.Ho, g.Wo, Co))
+    npix = B * g.Ho * g.Wo
+    tiles = ((Co + 127) // 128) * ((Ci + 127) // 128) * taps
+    ns = _nsplit(tiles, npix)
+    a = WgradArgs()
+    a.dY, a.X = _p(dy), _p(x)
+    partial = None
+    if ns == 1:
+        a.out = _p(gv)
+    else:
+        partial = torch.empty((ns, Co * taps * Ci), device=x.device, dtype=torch.float32)
+        a.partial = _p(partial)
+    if xf != XF_NONE:
+        assert stats is not None
+        a.scale, a.shift = _p(stats.scale), _p(stats.shift)
+    a.g = g
+    a.M, a.N, a.ldy, a.npix, a.nsplit = Co, Ci, Co, npix, ns
+    a.batch, a.sYb, a.sXb, a.sOb = 1, 0, 0, 0
+    a.xf, a.alpha = xf, 1.0
+    lib.call("vae_wgrad", C.byref(a), _stream())
+    if partial is not None:
+        lib.call("vae_reduce_splits", _p(partial), ns, Co * taps * Ci, _p(gv), _stream())
+    if bgrad_out is not None:
+        colsum(dy.view(npix, Co), bgrad_out)
+
+
+def colsum(x2d: torch.Tensor, out: torch.Tensor):
+    rows, Cc = x2d.shape
+    ws = torch.empty(((rows + 1023) // 1024, Cc), device=x2d.device, dtype=torch.float32)
+    lib.call("vae_colsum", _p(x2d), rows, Cc, _p(ws), _p(out), _stream())
+
+
+# ------------------------------------------------------------------ GroupNorm
+def _gn_nchunk(B: int, HW: int, Cc: int) -> int:
+    pr = max(1, 256 // (Cc // 4))
+    return max(1, min(2048 // max(B, 1), HW // (16 * pr) if HW >= 16 * pr else 1))
+
+
+def gn_stats(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, G: int = GN_GROUPS, eps: float = GN_EPS) -> Stats:
+    _chk_c(x, "gn_stats.x")
+    B, H, W, Cc = x.shape
+    HW = H * W
+    nch = _gn_nchunk(B, HW, Cc)
+    dev = x.device
+    ws = torch.empty((B, nch, G, 2), device=dev, dtype=torch.float32)
+    mean = torch.empty((B, G), device=dev, dtype=torch.float32)
+    rstd = torch.empty((B, G), device=dev, dtype=torch.float32)
+    scale = torch.empty((B, Cc), device=dev, dtype=torch.float32)
+    shift = torch.empty((B, Cc), device=dev, dtype=torch.float32)
+    lib.call("vae_gn_stats_partial", _p(x), B, HW, Cc, G, nch, _p(ws), _stream())
+    lib.call("vae_gn_stats_final", _p(ws), B, HW, Cc, G, nch, _p(gamma), _p(beta), eps, _p(mean), _p(rstd),
+             _p(scale), _p(shift), _stream())
+    return Stats(mean, rstd, scale, shift)
+
+
+def gn_apply(x: torch.Tensor, st: Stats, xf: int) -> torch.Tensor:
+    B, H, W, Cc = x.shape
+    y = torch.empty_like(x)
+    lib.call("vae_gn_apply", _p(x), _p(st.scale), _p(st.shift), B, H * W, Cc, xf, _p(y), _stream())
+    return y
+
+
+def gn_track(x: torch.Tensor, st: Stats) -> torch.Tensor:
+    """mean over (b,h,w) of |gn(x)| per channel (monitor.py:66), no tensor materialised."""
+    B, H, W, Cc = x.shape
+    HW = H * W
+    nch = _gn_nchunk(B, HW, Cc)
+    ws = torch.empty((B * nch, Cc), device=x.device, dtype=torch.float32)
+    out = torch.empty((Cc,), device=x.device, dtype=torch.float32)
+    lib.call("vae_gn_track_partial", _p(x), _p(st.scale), _p(st.shift), B, HW, Cc, nch, _p(ws), _stream())
+    lib.call("vae_track_final", _p(ws), B * nch, Cc, 1.0 / float(B * HW), _p(out), _stream())
+    return out
+
+
+def conv_track_buffer(M: int, Co: int, device) -> torch.Tensor:
+    return torch.empty(((M + 127) // 128, Co), device=device, dtype=torch.float32)
+
+
+def track_final(ws: torch.Tensor, count: int) -> torch.Tensor:
+    rows, Cc = ws.shape
+    out = torch.empty((Cc,), device=ws.device, dtype=torch.float32)
+    lib.call("vae_track_final", _p(ws), rows, Cc, 1.0 / float(count), _p(out), _stream())
+    return out
+
+
+def gn_bwd(x: torch.Tensor, g: torch.Tensor, st: Stats, gamma: torch.Tensor, beta: torch.Tensor, silu: bool,
+           add: Optional[torch.Tensor], dgamma: torch.Tensor, dbeta: torch.Tensor, G: int = GN_GROUPS) -> torch.Tensor:
+    _chk_c(x, "gn_bwd.x")
+    _chk_c(g, "gn_bwd.g")
+    assert g.shape == x.shape and (add is None or add.shape == x.shape)
+    B, H, W, Cc = x.shape
+    HW = H * W
+    nch = _gn_nchunk(B, HW, Cc)
+    dev = x.device
+    ws = torch.empty((B, nch, Cc, 2), device=dev, dtype=torch.float32)
+    coef = torch.empty((B, G, 2), device=dev, dtype=torch.float32)
+    dx = torch.empty_like(x)
+    s = _stream()
+    lib.call("vae_gn_bwd_partial", _p(x), _p(g), _p(st.mean), _p(st.rstd), _p(gamma), _p(beta), B, HW, Cc, G, nch,
+             int(silu), _p(ws), s)
+    lib.call("vae_gn_bwd_final", _p(ws), _p(st.rstd), _p(gamma), B, HW, Cc, G, nch, _p(dgamma), _p(dbeta), _p(coef), s)
+    lib.call("vae_gn_bwd_apply", _p(x), _p(g), _p(st.mean), _p(st.rstd), _p(gamma), _p(beta), _p(coef), _p(add), B, HW,
+             Cc, G, int(silu), _p(dx), s)
+    return dx
+
+
+# ------------------------------------------------------------------ batched GEMMs (attention)
+def _gemm_rows(A, Bm, out, M, N, K, sn, sk, alpha, z, sAb, sWb, sCb):
+    a = IgemmArgs()
+    a.A, a.W, a.C = _p(A), _p(Bm), _p(out)
+    a.g = ConvGeom(1, 1, M, K, 1, M, 1, 1, 0, 0, MODE_FWD)
+    a.M, a.N, a.K, a.ldc = M, N, K, N
+    a.sn, a.sk, a.st = sn, sk, 0
+    a.batch, a.sAb, a.sWb, a.sCb = z, sAb, sWb, sCb
+    a.xf, a.alpha = XF_NONE, alpha
+    lib.call("vae_igemm_rows", C.byref(a), _stream())
+
+
+def gemm_nt(A: torch.Tensor, Bm: torch.Tensor, alpha: float = 1.0) -> torch.Tensor:
+    """out[z] = alpha * A[z] @ Bm[z]^T ; A [z,M,K], Bm [z,N,K]."""
+    z, M, K = A.shape
+    N = Bm.shape[1]
+    out = torch.empty((z, M, N), device=A.device, dtype=torch.float32)
+    _gemm_rows(A, Bm, out, M, N, K, K, 1, alpha, z, M * K, N * K, M * N)
+    return out
+
+
+def gemm_nn(A: torch.Tensor, Bm: torch.Tensor, alpha: float = 1.0) -> torch.Tensor:
+    """out[z] = alpha * A[z] @ Bm[z] ; A [z,M,K], Bm [z,K,N]."""
+    z, M, K = A.shape
+    N = Bm.shape[2]
+    out = torch.empty((z, M, N), device=A.device, dtype=torch.float32)
+    _gemm_rows(A, Bm, out, M, N, K, 1, N, alpha, z, M * K, K * N, M * N)
+    return out
+
+
+def gemm_tn(A: torch.Tensor, Bm: torch.Tensor, alpha: float = 1.0) -> torch.Tensor:
+    """out[z] = alpha * A[z]^T @ Bm[z] ; A [z,K,M], Bm [z,K,N]."""
+    z, K, M = A.shape
+    N = Bm.shape[2]
+    out = torch.empty((z, M, N), device=A.device, dtype=torch.float32)
+    a = WgradArgs()
+    a.dY, a.X, a.out = _p(A), _p(Bm), _p(out)
+    a.g = ConvGeom(1, 1, K, N, 1, K, 1, 1, 0, 0, MODE_FWD)
+    a.M, a.N, a.ldy, a.npix, a.nsplit = M, N, M, K, 1
+    a.batch, a.sYb, a.sXb, a.sOb = z, K * M, K * N, M * N
+    a.xf, a.alpha = XF_NONE, alpha
+    lib.call("vae_wgrad", C.byref(a), _stream())
+    return out
+
+
+def softmax_rows_(S: torch.Tensor):
+    cols = S.shape[-1]
+    lib.call("vae_softmax_rows", _p(S), S.numel() // cols, cols, _stream())
+    return S
+
+
+def softmax_bwd_rows_(P: torch.Tensor, dP: torch.Tensor):
+    cols = P.shape[-1]
+    lib.call("vae_softmax_bwd_rows", _p(P), _p(dP), P.numel() // cols, cols, _stream())
+    return dP
+
+
+# ------------------------------------------------------------------ loss / sample / layout / optimizer
+def nchw_to_nhwc(x: torch.Tensor, cpad: Optional[int] = None) -> torch.Tensor:
+    _chk_c(x, "nchw_to_nhwc")
+    B, Cc, H, W = x.shape
+    cp = cpad or Cc
+    out = torch.empty((B, H, W, cp), device=x.device, dtype=torch.float32)
+    lib.call("vae_nchw_to_nhwc", _p(x), B, Cc, H * W, cp, _p(out), _stream())
+    return out
+
+
+def nhwc_to_nchw(x: torch.Tensor) -> torch.Tensor:
+    _chk_c(x, "nhwc_to_nchw")
+    B, H, W, Cc = x.shape
+    out = torch.empty((B, Cc, H, W), device=x.device, dtype=torch.float32)
+    lib.call("vae_nhwc_to_nchw", _p(x), B, Cc, H * W, _p(out), _stream())
+    return out
+
+
+def sample_kl(moments: torch.Tensor, eps: Optional[torch.Tensor]):
+    """moments [B,h,w,2L], eps [B,h,w,L] or None (mode) -> z [B,h,w,L], kl_partial [B,nblk]."""
+    _chk_c(moments, "sample_kl.moments")
+    B, h, w, L2 = moments.shape
+    L = L2 // 2
+    nblk = (h * w * L + 255) // 256
+    z = torch.empty((B, h, w, L), device=moments.device, dtype=torch.float32)
+    klp = torch.empty((B, nblk), device=moments.device, dtype=torch.float32)
+    lib.call("vae_sample_kl", _p(moments), _p(eps), B, h * w, L, _p(z), _p(klp), _stream())
+    return z, klp
+
+
+def sample_kl_bwd(moments, eps, dz, kl_weight: float):
+    B, h, w, L2 = moments.shape
+    L = L2 // 2
+    dm = torch.empty_like(moments)
+    lib.call("vae_sample_kl_bwd", _p(moments), _p(eps), _p(dz), B, h * w, L, float(kl_weight), _p(dm), _stream())
+    return dm
+
+
+def mse_kl_loss(recon: torch.Tensor, target: torch.Tensor, kl_partial: torch.Tensor, kl_weight: float) -> torch.Tensor:
+    """-> device scalars [mse_mean, kl_mean, total] (train.py:289-291)."""
+    n = recon.numel()
+    nblk = max(1, min(1024, (n + 4095) // 4096))
+    ws = torch.empty((nblk,), device=recon.device, dtype=torch.float32)
+    sc = torch.empty((3,), device=recon.device, dtype=torch.float32)
+    s = _stream()
+    lib.call("vae_mse_partial", _p(recon), _p(target), n, _p(ws), nblk, s)
+    B, kb = kl_partial.shape
+    lib.call("vae_loss_final", _p(ws), nblk, n, _p(kl_partial), B, kb, float(kl_weight), _p(sc), s)
+    return sc
+
+
+def mse_bwd(recon: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    d = torch.empty_like(recon)
+    lib.call("vae_mse_bwd", _p(recon), _p(target), recon.numel(), _p(d), _stream())
+    return d
+
+
+def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    o = torch.empty_like(a)
+    lib.call("vae_add", _p(a), _p(b), a.numel(), _p(o), _stream())
+    return o
+
+
+def sqnorm(g: torch.Tensor, out: torch.Tensor, ws: Optional[torch.Tensor] = None):
+    n = g.numel()
+    nblk = 2048
+    if ws is None:
+        ws = torch.empty((nblk,), device=g.device, dtype=torch.float32)
+    lib.call("vae_sqnorm", _p(g), n, _p(ws), nblk, _p(out), _stream())
+    return out
+
+
+def adamw(p, g, m, v, sqn: Optional[torch.Tensor], max_norm: float, lr: float, beta1: float, beta2: float, eps: float,
+          wd: float, step: int):
+    lib.call("vae_adamw", _p(p), _p(g), _p(m), _p(v), p.numel(), _p(sqn), float(max_norm), float(lr), float(beta1),
+             float(beta2), float(eps), float(wd), int(step), _stream())
