@@ -1,0 +1,164 @@
+"""End-to-end parity of the HIP engine against the CPU oracle (oracle/vae_oracle.py) on the same
+seeded weights / pixels / eps.  Tolerance per BASELINE.json north_star: 1e-4 relative for fp32
+outputs (reconstruction MSE, KL, per-channel stats); the inactivity mask must be identical."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TRACKED = ["encoder.conv_in", "encoder.down_blocks.0.resnets.0.norm1", "decoder.up_blocks.1.resnets.0.norm1"]
+
+
+def _rel(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def pair(cuda):
+    import vae_oracle as vo
+    from models.sdxl_vae_wrapper import SDXLVAEWrapper
+    o = vo.OracleWrapper(seed=42)
+    w = SDXLVAEWrapper("synthetic:1")
+    w.vae.load_state_dict(o.vae.state_dict())
+    w.to(cuda)
+    assert w.vae.arena.flat.is_cuda and w.vae.arena.owns(w.vae)
+    return o, w
+
+
+def _oracle_step(o, x, eps, klw):
+    import vae_oracle as vo
+    stats = {}
+    hooks = []
+    for name in TRACKED:
+        mod = o.vae.get_submodule(name)
+        hooks.append(mod.register_forward_hook(
+            lambda m, i, out, name=name: stats.__setitem__(name, vo.mean_abs_per_channel(out))))
+    for p in o.parameters():
+        p.grad = None
+    out = o(x, sample_posterior=True, eps=eps)
+    rec, kl, total = vo.losses(out, x, klw)
+    total.backward()
+    for h in hooks:
+        h.remove()
+    return out, rec, kl, total, stats
+
+
+@pytest.mark.parametrize("R,B,klw", [(32, 2, 1e-6), (64, 2, 1e-2)])
+def test_forward_backward_matches_oracle(pair, R, B, klw):
+    import vae_oracle as vo
+    o, w = pair
+    x, eps = vo.synthetic_pixels(B, R, 42), vo.synthetic_eps(B, R, 42)
+    out, rec, kl, total, stats = _oracle_step(o, x, eps, klw)
+
+    eng = w.vae.engine
+    got = {}
+    handles = [eng.add_tracker(w.vae.get_submodule(n), "output", lambda v, n=n: got.__setitem__(n, v)) for n in TRACKED]
+    res = eng.forward_backward(x.cuda(), eps.cuda(), klw)
+    for h in handles:
+        h.remove()
+    sc = res["scalars"].cpu()
+    assert abs(sc[0] - rec.item()) / rec.item() < 1e-4
+    assert abs(sc[1] - kl.item()) / abs(kl.item()) < 1e-4
+    assert abs(sc[2] - total.item()) / abs(total.item()) < 1e-4
+    assert _rel(res["reconstruction"].permute(0, 3, 1, 2), out["reconstruction"]) < 1e-4
+    with torch.no_grad():
+        mom_ref = o.vae.quant_conv(o.vae.encoder(x))
+    assert _rel(res["moments"].permute(0, 3, 1, 2), mom_ref) < 1e-4
+    assert _rel(res["latents"].permute(0, 3, 1, 2), out["latents_sampled"]) < 1e-4
+    # per-channel tracker stats (monitor.py:66) within 1e-4 relative, and identical inactivity mask
+    for n in TRACKED:
+        ref = stats[n]
+        v = got[n].cpu().numpy()
+        assert np.max(np.abs(v - ref) / ref) < 1e-4, n
+        thr = np.float32(np.median(ref))
+        assert np.array_equal(v < thr, ref < thr), n
+    # every gradient
+    worst = 0.0
+    oparams = dict(o.vae.named_parameters())
+    gmax = max(float(p.grad.abs().max()) for p in o.vae.parameters())
+    for name, p in w.vae.named_parameters():
+        ref = oparams[name].grad.double()
+        err = float((p.grad.detach().double().cpu() - ref).abs().max())
+        # attention to_k.bias has a mathematically zero gradient (softmax shift invariance): its
+        # reference value is rounding noise, hence the absolute floor tied to the global gradient scale
+        tol = 5e-4 * float(ref.abs().max()) + 1e-6 * gmax
+        worst = max(worst, err / (float(ref.abs().max()) + 1e-6 * gmax))
+        assert err <= tol, (name, err, tol)
+    gn_ref = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in o.vae.parameters()))
+    gn = torch.sqrt((w.vae.arena.grad.double() ** 2).sum()).cpu()
+    assert abs(gn - gn_ref) / gn_ref < 1e-4
+    print(f"R={R} worst grad rel err {worst:.2e}")
+
+
+def test_autograd_path_equals_fast_path(pair):
+    """SDXLVAEWrapper.forward + torch losses + .backward() (the reference's train.py:287-299 sequence)
+    must give the same numbers as the fused path."""
+    import vae_oracle as vo
+    o, w = pair
+    R, B, klw = 32, 2, 1e-3
+    x, eps = vo.synthetic_pixels(B, R, 7).cuda(), vo.synthetic_eps(B, R, 7).cuda()
+    res = w.vae.engine.forward_backward(x, eps, klw)
+    fast = w.vae.arena.grad.clone()
+    for p in w.parameters():
+        p.grad = None
+    d = w.vae.encode(x).latent_dist
+    z = d.sample(eps)
+    recon = w.vae.decode(z).sample
+    rec = F.mse_loss(recon.float(), x.float(), reduction="mean")
+    kl = d.kl().mean()
+    (rec + klw * kl).backward()
+    sc = res["scalars"].cpu()
+    assert abs(sc[0] - rec.item()) / rec.item() < 1e-6
+    assert abs(sc[1] - kl.item()) / abs(kl.item()) < 1e-5
+    gmax = float(fast.abs().max())
+    for name, p in w.vae.named_parameters():
+        assert p.grad is not None, name
+        ref = w.vae.arena.view_of(fast, p, w.vae.arena.offset_of[id(p)])
+        err = float((p.grad - ref).abs().max())
+        assert err <= 1e-5 * float(ref.abs().max()) + 1e-7 * gmax, (name, err)
+
+
+def test_foreign_hooks_get_real_tensors(pair):
+    """register_forward_hook / register_forward_pre_hook protocol (monitor.py:126-133) on fused layers."""
+    import vae_oracle as vo
+    o, w = pair
+    x = vo.synthetic_pixels(2, 32, 3)
+    names = ["encoder.down_blocks.0.resnets.0.norm1", "encoder.down_blocks.1.resnets.0.conv2",
+             "decoder.mid_block.attentions.0.to_q", "decoder.up_blocks.0"]
+    ref, got, handles = {}, {}, []
+    for n in names:
+        handles.append(o.vae.get_submodule(n).register_forward_hook(lambda m, i, out, n=n: ref.__setitem__(n, (i[0].detach(), out.detach()))))
+        handles.append(w.vae.get_submodule(n).register_forward_hook(lambda m, i, out, n=n: got.__setitem__(n, (i[0].detach().cpu(), out.detach().cpu()))))
+    pre = {}
+    handles.append(w.vae.get_submodule(names[0]).register_forward_pre_hook(lambda m, i: pre.__setitem__("x", i[0].shape)))
+    with torch.no_grad():
+        o(x, sample_posterior=False)
+        out = w(x.cuda(), sample_posterior=False)
+    for h in handles:
+        h.remove()
+    assert out["reconstruction"].shape == (2, 3, 32, 32)
+    assert pre["x"] == (2, 128, 32, 32)
+    for n in names:
+        assert got[n][0].shape == ref[n][0].shape and got[n][1].shape == ref[n][1].shape, n
+        assert _rel(got[n][0], ref[n][0]) < 1e-4 and _rel(got[n][1], ref[n][1]) < 1e-4, n
+    # hooks removed -> fused path again, same result
+    with torch.no_grad():
+        out2 = w(x.cuda(), sample_posterior=False)
+    assert _rel(out2["reconstruction"], out["reconstruction"]) < 1e-6
+
+
+def test_standalone_submodule_calls(pair):
+    import vae_oracle as vo
+    o, w = pair
+    gen = torch.Generator().manual_seed(0)
+    t = torch.randn(1, 128, 8, 8, generator=gen)
+    with torch.no_grad():
+        r = w.vae.encoder.down_blocks[0].resnets[0](t.cuda())
+        ref = o.vae.encoder.down_blocks[0].resnets[0](t)
+        assert _rel(r, ref) < 1e-4
+        g = w.vae.encoder.down_blocks[0].resnets[0].norm1(t.cuda())
+        assert _rel(g, o.vae.encoder.down_blocks[0].resnets[0].norm1(t)) < 1e-5

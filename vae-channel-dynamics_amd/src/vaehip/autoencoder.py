@@ -214,21 +214,31 @@ class ParamArena:
 
     def __init__(self, module: nn.Module, device: torch.device):
         self.entries: List[Tuple[str, nn.Parameter, int, int]] = []
-        off = 0
-        for name, p in module.named_parameters():
-            self.entries.append((name, p, off, p.numel()))
-            off += (p.numel() + 3) // 4 * 4
-        self.total = off
         self.device = torch.device(device)
+        owners = []
+        off = 0
+        for mname, mod in module.named_modules():
+            for pname, p in mod._parameters.items():
+                if p is None:
+                    continue
+                owners.append((mod, pname, (mname + "." if mname else "") + pname, p, off))
+                off += (p.numel() + 3) // 4 * 4
+        self.total = off
         self.flat = torch.zeros(off, device=device, dtype=torch.float32)
         self.grad = torch.zeros(off, device=device, dtype=torch.float32)
         self.offset_of: Dict[int, int] = {}
-        for name, p, o, n in self.entries:
+        for mod, pname, name, p, o in owners:
             view = self.view_of(self.flat, p, o)
-            if p.device.type != "meta":
+            if p.device.type == "meta":
+                # first materialisation: the meta placeholder is replaced by a real leaf Parameter
+                p = nn.Parameter(view, requires_grad=p.requires_grad)
+                mod._parameters[pname] = p
+            else:
+                # re-homing (e.g. after .to(device)): keep the Parameter object (optimizers hold it)
                 view.copy_(p.data.to(device=device, dtype=torch.float32))
-            p.data = view
-            p.grad = None
+                p.data = view
+                p.grad = None
+            self.entries.append((name, p, o, p.numel()))
             self.offset_of[id(p)] = o
 
     @staticmethod

@@ -1,0 +1,486 @@
+"""Execution engine of the SDXL-VAE train step on the HIP kernels.
+
+The engine walks the module tree itself (encode -> sample -> decode, the composition of
+reference src/models/sdxl_vae_wrapper.py:42-77) and records a tape of backward closures, so
+GroupNorm+SiLU can be fused into the consuming convolution and the normalised activations
+never touch HBM.  The torch.nn hook protocol the reference's plugins rely on
+(monitor.py:126-133, sdxl_vae_wrapper.py:104-107) is honoured: a module that carries foreign
+forward hooks gets its input/output materialised and the hooks are called synchronously;
+the shipped metric `mean_abs_activation_per_channel` (monitor.py:66) is served by fused
+device-side reductions instead (add_tracker), without any tensor or host sync.
+"""
+from __future__ import annotations
+
+import weakref
+from typing import Callable, Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import XF_AFFINE, XF_AFFINE_SILU, XF_NONE, Stats
+
+_TRACK_C = {4, 8, 16, 32, 64, 128, 256, 512, 1024}
+
+
+class _TrackHandle:
+    def __init__(self, store: dict, key, point: str, sink):
+        self._s, self._k, self._p, self._f = store, key, point, sink
+
+    def remove(self):
+        lst = self._s.get(self._k, {}).get(self._p, [])
+        if self._f in lst:
+            lst.remove(self._f)
+
+
+class Engine:
+    def __init__(self, vae: nn.Module):
+        self._vae = weakref.ref(vae)
+        self._trackers: Dict[int, Dict[str, List[Callable]]] = {}
+        self._gtarget: Optional[torch.Tensor] = None
+        self.reducer = None  # optional DP bucket reducer with .ready(low_offset)
+        self._low: Dict[int, int] = {}
+        self._ident: Dict[tuple, Stats] = {}
+
+    # ------------------------------------------------------------------ plumbing
+    @property
+    def vae(self):
+        return self._vae()
+
+    @property
+    def arena(self):
+        return self.vae.arena
+
+    def _require_gpu(self):
+        if self.arena.flat.device.type != "cuda":
+            raise RuntimeError("the VAE parameters are on %s; the HIP engine needs a GPU (there is no CPU fallback); "
+                               "call .to('cuda') first" % self.arena.flat.device)
+
+    def _g(self, p: Optional[nn.Parameter]):
+        return None if p is None else self.arena.grad_view(p, self._gtarget)
+
+    def _done(self, module: nn.Module):
+        if self.reducer is not None:
+            k = id(module)
+            if k not in self._low:
+                self._low[k] = self.arena.block_low_offset(module)
+            self.reducer.ready(self._low[k])
+
+    # ------------------------------------------------------------------ trackers and hooks
+    def add_tracker(self, module: nn.Module, point: str, sink: Callable[[torch.Tensor], None]):
+        """fused `mean_abs_activation_per_channel` for `module`'s input or output: sink(tensor[C]) per forward."""
+        assert point in ("input", "output")
+        self._trackers.setdefault(id(module), {}).setdefault(point, []).append(sink)
+        return _TrackHandle(self._trackers, id(module), point, sink)
+
+    def _tracked(self, m, point):
+        d = self._trackers.get(id(m))
+        return d.get(point) if d else None
+
+    def _mean_abs(self, t: torch.Tensor) -> torch.Tensor:
+        B, Cc = t.shape[0], t.shape[-1]
+        if Cc in _TRACK_C:
+            key = (B, Cc, t.device)
+            st = self._ident.get(key)
+            if st is None:
+                one = torch.ones((B, Cc), device=t.device)
+                st = Stats(None, None, one, torch.zeros_like(one))
+                self._ident[key] = st
+            return ops.gn_track(t.reshape(B, -1, 1, Cc), st)
+        return t.abs().mean(dim=tuple(range(t.ndim - 1)))
+
+    @staticmethod
+    def _present(m, t: torch.Tensor) -> torch.Tensor:
+        """NHWC buffer -> the tensor a torch hook on `m` expects (NCHW-logical view; [B,T,C] for Linear)."""
+        if isinstance(m, nn.Linear):
+            return t.reshape(t.shape[0], -1, t.shape[-1])
+        return t.permute(0, 3, 1, 2)
+
+    def _pre(self, m, make_in):
+        sinks = self._tracked(m, "input")
+        if m._forward_pre_hooks or sinks:
+            t = make_in()
+            if sinks:
+                v = self._mean_abs(t)
+                for s in sinks:
+                    s(v)
+            for h in list(m._forward_pre_hooks.values()):
+                h(m, (self._present(m, t),))
+
+    def _post(self, m, make_in, out: torch.Tensor, tracked_already=False):
+        sinks = None if tracked_already else self._tracked(m, "output")
+        if sinks:
+            v = self._mean_abs(out)
+            for s in sinks:
+                s(v)
+        if m._forward_hooks:
+            tin = self._present(m, make_in())
+            for h in list(m._forward_hooks.values()):
+                h(m, (tin,), self._present(m, out))
+
+    @staticmethod
+    def _no_hooks(m, what):
+        if m is not None and (m._forward_hooks or m._forward_pre_hooks):
+            raise NotImplementedError(f"forward hooks on {what} are not supported: it is fused into the adjacent "
+                                      f"convolution. Hook the GroupNorm before it or the convolution after it.")
+
+    # ------------------------------------------------------------------ leaves (forward)
+    def _gn(self, norm, x: torch.Tensor) -> Stats:
+        self._pre(norm, lambda: x)
+        st = ops.gn_stats(x, norm.weight, norm.bias, norm.num_groups, norm.eps)
+        sinks = self._tracked(norm, "output")
+        if sinks:
+            v = ops.gn_track(x, st)
+            for s in sinks:
+                s(v)
+        if norm._forward_hooks:
+            self._post(norm, lambda: x, ops.gn_apply(x, st, XF_AFFINE), tracked_already=True)
+        return st
+
+    def _conv(self, m, x: torch.Tensor, xf: int, st: Optional[Stats], res: Optional[torch.Tensor] = None) -> torch.Tensor:
+        kind = getattr(m, "kind", "c1")
+        cache = {}
+
+        def make_in():
+            if "t" not in cache:
+                t = x if xf == XF_NONE else ops.gn_apply(x, st, xf)
+                ci = m.weight.shape[1]
+                cache["t"] = t if t.shape[-1] == ci else t[..., :ci]
+            return cache["t"]
+
+        self._pre(m, make_in)
+        sinks = self._tracked(m, "output")
+        fuse_res = res is not None and not m._forward_hooks and not sinks
+        tb = None
+        if sinks:
+            ho, wo = ops.out_hw(kind, x.shape[1], x.shape[2])
+            tb = ops.conv_track_buffer(x.shape[0] * ho * wo, m.weight.shape[0], x.device)
+        y = ops.conv_fwd(x, m.weight, m.bias, kind, xf=xf, stats=st, res=res if fuse_res else None, track=tb)
+        if sinks:
+            v = ops.track_final(tb, y.shape[0] * y.shape[1] * y.shape[2])
+            for s in sinks:
+                s(v)
+        if m._forward_hooks:
+            self._post(m, make_in, y, tracked_already=True)
+        if res is not None and not fuse_res:
+            y = ops.add(y, res)
+        return y
+
+    def _conv_bwd(self, m, x, dy, xf, st, need_dx=True):
+        kind = getattr(m, "kind", "c1")
+        ops.conv_wgrad(dy, x, kind, self._g(m.weight), self._g(m.bias), xf=xf, stats=st)
+        if need_dx:
+            return ops.conv_dgrad(dy, m.weight, kind, (x.shape[1], x.shape[2]))
+        return None
+
+    def _gn_bwd(self, norm, x, g, st, silu, add):
+        return ops.gn_bwd(x, g, st, norm.weight, norm.bias, silu, add, self._g(norm.weight), self._g(norm.bias),
+                          norm.num_groups)
+
+    # ------------------------------------------------------------------ blocks
+    def _plain_conv(self, m, x, tape, need_dx=True, owner=None):
+        y = self._conv(m, x, XF_NONE, None)
+        if tape is not None:
+            def bwd(d):
+                dx = self._conv_bwd(m, x, d, XF_NONE, None, need_dx)
+                self._done(owner or m)
+                return dx
+            tape.append(bwd)
+        return y
+
+    def _resnet(self, r, x, tape, notify=True):
+        self._no_hooks(r.nonlinearity, "ResnetBlock2D.nonlinearity")
+        self._no_hooks(r.dropout, "ResnetBlock2D.dropout")
+        self._pre(r, lambda: x)
+        st1 = self._gn(r.norm1, x)
+        h = self._conv(r.conv1, x, XF_AFFINE_SILU, st1)
+        st2 = self._gn(r.norm2, h)
+        sc = self._conv(r.conv_shortcut, x, XF_NONE, None) if r.conv_shortcut is not None else x
+        out = self._conv(r.conv2, h, XF_AFFINE_SILU, st2, res=sc)
+        self._post(r, lambda: x, out)
+        if tape is not None:
+            def bwd(dout):
+                g2 = self._conv_bwd(r.conv2, h, dout, XF_AFFINE_SILU, st2)
+                dh = self._gn_bwd(r.norm2, h, g2, st2, True, None)
+                g1 = self._conv_bwd(r.conv1, x, dh, XF_AFFINE_SILU, st1)
+                dsc = self._conv_bwd(r.conv_shortcut, x, dout, XF_NONE, None) if r.conv_shortcut is not None else dout
+                dx = self._gn_bwd(r.norm1, x, g1, st1, True, dsc)
+                if notify is True:
+                    self._done(r)
+                elif notify is not False:
+                    self._done(notify)  # an enclosing module whose parameters are all final now
+                return dx
+            tape.append(bwd)
+        return out
+
+    def _attention(self, a, x, tape, notify=True):
+        self._pre(a, lambda: x)
+        B, H, W, Cc = x.shape
+        T = H * W
+        scale = float(Cc) ** -0.5
+        st = self._gn(a.group_norm, x)
+        q = self._conv(a.to_q, x, XF_AFFINE, st)
+        k = self._conv(a.to_k, x, XF_AFFINE, st)
+        v = self._conv(a.to_v, x, XF_AFFINE, st)
+        qf, kf, vf = q.view(B, T, Cc), k.view(B, T, Cc), v.view(B, T, Cc)
+        P = ops.softmax_rows_(ops.gemm_nt(qf, kf, scale))
+        o = ops.gemm_nn(P, vf).view(B, H, W, Cc)
+        self._no_hooks(a.to_out[1], "Attention.to_out.1 (dropout)")
+        out = self._conv(a.to_out[0], o, XF_NONE, None, res=x)
+        self._post(a, lambda: x, out)
+        if tape is not None:
+            def bwd(dout):
+                do = self._conv_bwd(a.to_out[0], o, dout, XF_NONE, None).view(B, T, Cc)
+                dP = ops.gemm_nt(do, vf)
+                dv = ops.gemm_tn(P, do)
+                dS = ops.softmax_bwd_rows_(P, dP)
+                dq = ops.gemm_nn(dS, kf, scale)
+                dk = ops.gemm_tn(dS, qf, scale)
+                g = self._conv_bwd(a.to_q, x, dq.view(B, H, W, Cc), XF_AFFINE, st)
+                g = ops.add(g, self._conv_bwd(a.to_k, x, dk.view(B, H, W, Cc), XF_AFFINE, st))
+                g = ops.add(g, self._conv_bwd(a.to_v, x, dv.view(B, H, W, Cc), XF_AFFINE, st))
+                dx = self._gn_bwd(a.group_norm, x, g, st, False, dout)
+                if notify:
+                    self._done(a)
+                return dx
+            tape.append(bwd)
+        return out
+
+    def _mid(self, mb, x, tape):
+        self._pre(mb, lambda: x)
+        # registration order (attentions, resnets) differs from execution order, so the DP watermark
+        # only moves once the whole mid block is final: after resnets[0]'s backward (last on the tape)
+        h = self._resnet(mb.resnets[0], x, tape, notify=mb)
+        h = self._attention(mb.attentions[0], h, tape, notify=False)
+        h = self._resnet(mb.resnets[1], h, tape, notify=False)
+        self._post(mb, lambda: x, h)
+        return h
+
+    def _sampler(self, s, x, tape):
+        self._pre(s, lambda: x)
+        y = self._plain_conv(s.conv, x, tape, owner=s)
+        self._post(s, lambda: x, y)
+        return y
+
+    def _updown_block(self, blk, x, tape):
+        self._pre(blk, lambda: x)
+        h = x
+        for r in blk.resnets:
+            h = self._resnet(r, h, tape)
+        extra = getattr(blk, "downsamplers", None) or getattr(blk, "upsamplers", None)
+        if extra is not None:
+            h = self._sampler(extra[0], h, tape)
+        self._post(blk, lambda: x, h)
+        return h
+
+    def _norm_act_conv(self, owner, x, tape):
+        norm, act, conv = owner.conv_norm_out, owner.conv_act, owner.conv_out
+        self._no_hooks(act, "conv_act")
+        st = self._gn(norm, x)
+        y = self._conv(conv, x, XF_AFFINE_SILU, st)
+        if tape is not None:
+            def bwd(d):
+                g = self._conv_bwd(conv, x, d, XF_AFFINE_SILU, st)
+                dx = self._gn_bwd(norm, x, g, st, True, None)
+                self._done(conv)
+                self._done(norm)
+                return dx
+            tape.append(bwd)
+        return y
+
+    # ------------------------------------------------------------------ encoder / decoder on NHWC
+    def encoder_nhwc(self, x4: torch.Tensor, tape) -> torch.Tensor:
+        enc = self.vae.encoder
+        self._pre(enc, lambda: x4[..., :3])
+        h = self._plain_conv(enc.conv_in, x4, tape, need_dx=False)
+        for blk in enc.down_blocks:
+            h = self._updown_block(blk, h, tape)
+        h = self._mid(enc.mid_block, h, tape)
+        h = self._norm_act_conv(enc, h, tape)
+        self._post(enc, lambda: x4[..., :3], h)
+        return h
+
+    def encode_nhwc(self, x4, tape):
+        return self._plain_conv(self.vae.quant_conv, self.encoder_nhwc(x4, tape), tape)
+
+    def decoder_nhwc(self, z: torch.Tensor, tape) -> torch.Tensor:
+        dec = self.vae.decoder
+        self._pre(dec, lambda: z)
+        h = self._plain_conv(dec.conv_in, z, tape)
+        h = self._mid(dec.mid_block, h, tape)
+        for blk in dec.up_blocks:
+            h = self._updown_block(blk, h, tape)
+        h = self._norm_act_conv(dec, h, tape)
+        self._post(dec, lambda: z, h)
+        return h
+
+    def decode_nhwc(self, z, tape):
+        return self.decoder_nhwc(self._plain_conv(self.vae.post_quant_conv, z, tape), tape)
+
+    def run_tape(self, tape: list, grad: torch.Tensor, gtarget: torch.Tensor):
+        self._gtarget = gtarget
+        try:
+            while tape:
+                grad = tape.pop()(grad)
+        finally:
+            self._gtarget = None
+        return grad
+
+    # ------------------------------------------------------------------ fused train / eval step (fast path)
+    def forward_backward(self, pixel_values: torch.Tensor, eps: Optional[torch.Tensor], kl_weight: float,
+                         sample_posterior: bool = True, generator: Optional[torch.Generator] = None):
+        """fwd + loss (train.py:289-291) + bwd; gradients are WRITTEN into arena.grad (no accumulation).
+        Returns dict(scalars[3]=mse,kl,total on device, reconstruction, moments, latents) as NHWC buffers."""
+        self._require_gpu()
+        B, Cc, H, W = pixel_values.shape
+        pv = pixel_values.contiguous()
+        x4 = ops.nchw_to_nhwc(pv, 4)
+        tgt = ops.nchw_to_nhwc(pv, 3)
+        te: list = []
+        td: list = []
+        mom = self.encode_nhwc(x4, te)
+        e = self._eps_nhwc(eps, mom, sample_posterior, generator)
+        z, klp = ops.sample_kl(mom, e)
+        recon = self.decode_nhwc(z, td)
+        scalars = ops.mse_kl_loss(recon, tgt, klp, kl_weight)
+        drec = ops.mse_bwd(recon, tgt)
+        self.arena.attach_grads()
+        dz = self.run_tape(td, drec, self.arena.grad)
+        dmom = ops.sample_kl_bwd(mom, e, dz, kl_weight)
+        self.run_tape(te, dmom, self.arena.grad)
+        if self.reducer is not None:
+            self.reducer.ready(0)
+        return {"scalars": scalars, "reconstruction": recon, "moments": mom, "latents": z, "kl_partial": klp}
+
+    @torch.no_grad()
+    def forward_eval(self, pixel_values: torch.Tensor, eps: Optional[torch.Tensor] = None, sample_posterior: bool = False,
+                     kl_weight: float = 0.0, generator: Optional[torch.Generator] = None):
+        self._require_gpu()
+        pv = pixel_values.contiguous()
+        x4 = ops.nchw_to_nhwc(pv, 4)
+        tgt = ops.nchw_to_nhwc(pv, 3)
+        mom = self.encode_nhwc(x4, None)
+        e = self._eps_nhwc(eps, mom, sample_posterior, generator)
+        z, klp = ops.sample_kl(mom, e)
+        recon = self.decode_nhwc(z, None)
+        scalars = ops.mse_kl_loss(recon, tgt, klp, kl_weight)
+        return {"scalars": scalars, "reconstruction": recon, "moments": mom, "latents": z, "kl_partial": klp}
+
+    @staticmethod
+    def _eps_nhwc(eps, mom, sample_posterior, generator):
+        if not sample_posterior:
+            return None
+        B, h, w, L2 = mom.shape
+        if eps is None:
+            return torch.randn((B, h, w, L2 // 2), device=mom.device, dtype=torch.float32, generator=generator)
+        assert eps.shape == (B, L2 // 2, h, w), eps.shape
+        return ops.nchw_to_nhwc(eps.to(mom.device).contiguous())
+
+    # ------------------------------------------------------------------ autograd-compatible path
+    def encode_autograd(self, x: torch.Tensor) -> torch.Tensor:
+        self._require_gpu()
+        return _EncodeFn.apply(self, torch.is_grad_enabled(), x, *self._params_of(self.vae.encoder, self.vae.quant_conv))
+
+    def decode_autograd(self, z: torch.Tensor) -> torch.Tensor:
+        self._require_gpu()
+        return _DecodeFn.apply(self, torch.is_grad_enabled(), z, *self._params_of(self.vae.post_quant_conv, self.vae.decoder))
+
+    @staticmethod
+    def _params_of(*mods):
+        out = []
+        for m in mods:
+            out.extend(m.parameters())
+        return out
+
+    # ------------------------------------------------------------------ stand-alone module calls (inference only)
+    def _standalone(self, x: torch.Tensor):
+        self._require_gpu()
+        if torch.is_grad_enabled() and x.requires_grad:
+            raise RuntimeError("sub-module calls are inference-only; differentiate through SDXLVAEWrapper.forward / "
+                               "vae.encode / vae.decode")
+        if x.ndim == 3:  # [B,T,C] linear input
+            return x.contiguous().unsqueeze(1)
+        return x.permute(0, 2, 3, 1).contiguous()
+
+    def leaf_conv(self, m, x):
+        t = self._standalone(x)
+        if t.shape[-1] == 3:
+            t = torch.nn.functional.pad(t, (0, 1))
+        with torch.no_grad():
+            return self._conv(m, t, XF_NONE, None).permute(0, 3, 1, 2)
+
+    def leaf_linear(self, m, x):
+        t = self._standalone(x)
+        with torch.no_grad():
+            y = self._conv(m, t, XF_NONE, None)
+        return y.squeeze(1) if x.ndim == 3 else y.permute(0, 3, 1, 2)
+
+    def leaf_groupnorm(self, m, x):
+        t = self._standalone(x)
+        with torch.no_grad():
+            st = ops.gn_stats(t, m.weight, m.bias, m.num_groups, m.eps)
+            return ops.gn_apply(t, st, XF_AFFINE).permute(0, 3, 1, 2)
+
+    def block_call(self, m, x):
+        from . import autoencoder as A
+        t = self._standalone(x)
+        with torch.no_grad():
+            if isinstance(m, A.ResnetBlock2D):
+                y = self._resnet(m, t, None)
+            elif isinstance(m, A.Attention):
+                y = self._attention(m, t, None)
+            elif isinstance(m, A.UNetMidBlock2D):
+                y = self._mid(m, t, None)
+            elif isinstance(m, (A.DownEncoderBlock2D, A.UpDecoderBlock2D)):
+                y = self._updown_block(m, t, None)
+            elif isinstance(m, (A.Downsample2D, A.Upsample2D)):
+                y = self._sampler(m, t, None)
+            elif isinstance(m, A.Encoder):
+                y = self.encoder_nhwc(torch.nn.functional.pad(t, (0, 1)) if t.shape[-1] == 3 else t, None)
+            elif isinstance(m, A.Decoder):
+                y = self.decoder_nhwc(t, None)
+            else:
+                raise NotImplementedError(type(m).__name__)
+        return y.permute(0, 3, 1, 2)
+
+
+class _EncodeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, eng: Engine, record: bool, x: torch.Tensor, *params):
+        need = record and any(p.requires_grad for p in params)
+        tape = [] if need else None
+        x4 = ops.nchw_to_nhwc(x.detach().to(dtype=torch.float32).contiguous(), 4)
+        mom = eng.encode_nhwc(x4, tape)
+        ctx.eng, ctx.tape, ctx.params = eng, tape, params
+        return mom.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dmom):
+        eng = ctx.eng
+        if ctx.tape is None:
+            raise RuntimeError("backward through a forward that recorded no tape")
+        gbuf = torch.zeros_like(eng.arena.grad)
+        eng.run_tape(ctx.tape, dmom.permute(0, 2, 3, 1).contiguous(), gbuf)
+        grads = [eng.arena.grad_view(p, gbuf) if p.requires_grad else None for p in ctx.params]
+        return (None, None, None, *grads)
+
+
+class _DecodeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, eng: Engine, record: bool, z: torch.Tensor, *params):
+        need = record and (z.requires_grad or any(p.requires_grad for p in params))
+        tape = [] if need else None
+        zz = z.detach().to(dtype=torch.float32).permute(0, 2, 3, 1).contiguous()
+        rec = eng.decode_nhwc(zz, tape)
+        ctx.eng, ctx.tape, ctx.params = eng, tape, params
+        return rec.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, drec):
+        eng = ctx.eng
+        if ctx.tape is None:
+            raise RuntimeError("backward through a forward that recorded no tape")
+        gbuf = torch.zeros_like(eng.arena.grad)
+        dz = eng.run_tape(ctx.tape, drec.permute(0, 2, 3, 1).contiguous(), gbuf)
+        grads = [eng.arena.grad_view(p, gbuf) if p.requires_grad else None for p in ctx.params]
+        return (None, None, dz.permute(0, 3, 1, 2), *grads)
