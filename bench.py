@@ -1,0 +1,185 @@
+#!/usr/bin/env python
+"""Throughput of the SDXL-VAE fine-tune step (fwd + loss + bwd + clip + AdamW, tracking on) on
+N MI355X GPUs of one node.  One process per GPU (torch.distributed / RCCL when N > 1).
+
+Workload at every N (weak scaling) = BASELINE.json configs[1]: SDXL-VAE, 256x256 synthetic RGB,
+batch 16 per GPU, fp32, ActivityMonitor on the 3 shipped layers + classifier, no intervention.
+
+Prints ONE JSON line on rank 0 (see the contract in the task statement) with two extra objects:
+  roofline     -- dominant kernel's achieved TFLOP/s (HIP events over the timed region) vs the fp32 MFMA peak
+  cpu_baseline -- the CPU oracle (plain PyTorch restatement of the reference path) on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "vae-channel-dynamics_amd", "src"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+RES = 256
+BATCH_PER_GPU = 16
+MFMA_F32_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix peak
+TRACKING_CFG = {
+    "enabled": True, "track_interval": 20,
+    "target_layers": [
+        {"name": "vae.encoder.conv_in", "capture_point": "output", "metrics": ["mean_abs_activation_per_channel"]},
+        {"name": "vae.encoder.down_blocks.0.resnets.0.norm1", "capture_point": "output", "metrics": ["mean_abs_activation_per_channel"]},
+        {"name": "vae.decoder.up_blocks.1.resnets.0.norm1", "capture_point": "output", "metrics": ["mean_abs_activation_per_channel"]},
+    ],
+}
+CLASSIFY_CFG = {
+    "enabled": True, "method": "threshold_groupnorm_activity", "threshold": 0.2,
+    "target_metric_key": "mean_abs_activation_per_channel",
+    "layers_to_classify": ["vae.encoder.down_blocks.0.resnets.0.norm1.output", "vae.decoder.up_blocks.1.resnets.0.norm1.output"],
+}
+
+
+def cpu_baseline(max_seconds: float = 40.0):
+    """reference-equivalent CPU path (PyTorch oracle) on the host cores: one full train step
+    (fwd+loss+bwd+clip+AdamW, 3 tracker hooks) on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import vae_oracle as vo
+    cores = torch.get_num_threads()
+    o = vo.OracleWrapper(seed=42)
+    hooks = []
+    for conf in TRACKING_CFG["target_layers"]:
+        mod = o.get_submodule(conf["name"])
+        hooks.append(mod.register_forward_hook(lambda m, i, out: vo.mean_abs_per_channel(out)))
+    tr = vo.OracleTrainer(o, max_steps=100)
+    tr.step(vo.synthetic_pixels(1, 64, 1), vo.synthetic_eps(1, 64, 1))  # warm-up (library init)
+    b = 1
+    x, e = vo.synthetic_pixels(b, RES, 42), vo.synthetic_eps(b, RES, 42)
+    t0 = time.perf_counter()
+    tr.step(x, e)
+    dt = time.perf_counter() - t0
+    steps = 1
+    while dt < 10.0 and steps < 4:
+        t1 = time.perf_counter()
+        tr.step(x, e)
+        dt += time.perf_counter() - t1
+        steps += 1
+    for h in hooks:
+        h.remove()
+    return {"value": round(b * steps / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"{steps} full train step(s) at batch {b}, 256x256, fp32, torch CPU ({cores} threads); "
+                      f"oracle = plain-PyTorch restatement of the reference diffusers path"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="per-GPU batch (default = BASELINE config)")
+    ap.add_argument("--res", type=int, default=RES)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tracking", action="store_true", help="A/B switch for the tracker-overhead measurement")
+    ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP-event timing")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from models.sdxl_vae_wrapper import SDXLVAEWrapper
+    from tracking.monitor import ActivityMonitor
+    from classification.classifier import RegionClassifier
+    from vaehip.trainer import HipTrainer
+    from vaehip import ops
+
+    torch.manual_seed(42)
+    w = SDXLVAEWrapper("synthetic:42", device=dev)
+    trainer = HipTrainer(w, lr=1e-5, max_grad_norm=1.0, kl_weight=1e-6, lr_warmup_steps=100,
+                         max_train_steps=10000, scheduler_steps_per_update=world)
+    monitor = None if args.no_tracking else ActivityMonitor(w, TRACKING_CFG)
+    classifier = None if args.no_tracking else RegionClassifier(w.vae, CLASSIFY_CFG)
+
+    gen = torch.Generator(device=dev).manual_seed(42 + rank)
+    B, R = args.batch, args.res
+    x = torch.rand((B, 3, R, R), device=dev, generator=gen) * 2 - 1  # resident in HBM before the timed region
+    eps = torch.randn((B, 4, R // 8, R // 8), device=dev, generator=gen)
+
+    def one_step():
+        trainer.train_step(x, eps)
+        if monitor is not None and trainer.global_step % TRACKING_CFG["track_interval"] == 0:
+            monitor.step(trainer.global_step)
+            data = monitor.get_data_for_step(trainer.global_step)
+            if data:
+                classifier.classify(data, trainer.global_step)
+
+    for _ in range(args.warmup):
+        one_step()
+    prof = None
+    if rank == 0 and not args.no_profile:
+        prof = ops.LaunchProfiler()
+        ops.PROFILER = prof
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    ops.PROFILER = None
+    tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    sc = trainer.last["scalars"].cpu().tolist()
+
+    if rank == 0:
+        roof = None
+        kernels = {}
+        if prof is not None:
+            summ = prof.summary()
+            tot_ms = sum(v["ms"] for v in summ.values())
+            for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
+                kernels[k] = {"launches_per_step": v["launches"] / args.steps, "ms_per_step": round(v["ms"] / args.steps, 3),
+                              "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else None}
+            dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
+            ach = dom[1]["flops"] / (dom[1]["ms"] * 1e-3) / 1e12
+            allk = sum(v["flops"] for v in summ.values()) / (tot_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                    "kernel": dom[0], "launches": dom[1]["launches"],
+                    "avg_launch_ms": round(dom[1]["ms"] / dom[1]["launches"], 4),
+                    "all_contraction_kernels_tflops": round(allk, 2),
+                    "contraction_ms_per_step": round(tot_ms / args.steps, 2)}
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            cpu = cpu_baseline()
+        line = {
+            "metric": "images/sec SDXL-VAE train step @256x256 (tracking on)",
+            "value": round(world * B * args.steps / dt, 3), "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: SDXL-VAE {R}x{R} synthetic RGB, batch {B}/GPU, fp32, "
+                                   f"tracking {'off' if args.no_tracking else 'on (3 layers) + classifier'}, no nudge; "
+                                   f"random-init weights (synthetic:42)",
+                       "global_batch": world * B, "resolution": R, "parallelism": f"dp{world}"},
+            "loss": {"mse": sc[0], "kl": sc[1], "total": sc[2]},
+            "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

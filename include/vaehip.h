@@ -169,7 +169,8 @@ int vae_adamw(float* p, const float* g, float* m, float* v, int64_t n, const flo
               float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
               int32_t step, void* stream);
 /* dead-weight scan (deadneuron.py:78-115): counts per segment of |w|<thr, and sum|w|;
- * seg_off [nseg+1] element offsets into w; out_counts [nseg] (u64), out_abssum [nseg] (double) */
+ * seg_off [nseg][2] = {begin,end} element offsets into w (segments need not be adjacent);
+ * out_counts [nseg] (u64), out_abssum [nseg] (double); one workgroup per segment, fixed order  */
 int vae_dead_scan(const float* w, const int64_t* seg_off, int32_t nseg, float thr,
                   unsigned long long* out_counts, double* out_abssum, void* stream);
 int vae_dead_scan_adaptive(const float* w, const int64_t* seg_off, int32_t nseg, float thr, int32_t use_fixed,

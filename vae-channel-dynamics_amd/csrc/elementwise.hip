@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void dead_scan_kernel(const float* __restrict_
                                                         unsigned long long* __restrict__ counts, double* __restrict__ abssum) {
   __shared__ double red[4];
   const int s = blockIdx.x;
-  const int64_t b = seg_off[s], e = seg_off[s + 1];
+  const int64_t b = seg_off[2 * s], e = seg_off[2 * s + 1];
   double sum = 0.0, cnt = 0.0;
   for (int64_t i = b + threadIdx.x; i < e; i += 256) {
     const float a = fabsf(w[i]);
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void dead_scan_adaptive_kernel(const float* __
                                                                  unsigned long long* __restrict__ counts) {
   __shared__ double red[4];
   const int s = blockIdx.x;
-  const int64_t b = seg_off[s], e = seg_off[s + 1];
+  const int64_t b = seg_off[2 * s], e = seg_off[2 * s + 1];
   const float at = athr[s];
   double cnt = 0.0;
   for (int64_t i = b + threadIdx.x; i < e; i += 256) {

@@ -1,0 +1,84 @@
+"""Data parallelism for the flat gradient arena: one process per GPU, torch.distributed
+(backend "nccl" == RCCL over xGMI on ROCm; "gloo" on CPU for tests).
+
+Replaces the DDP wrap created by accelerate.prepare in the reference (src/train.py:204-211):
+the gradient mean is a handful of large all-reduces over contiguous arena slices, launched from
+the END of the arena (decoder, whose gradients are final first) while the encoder backward is
+still running.  Device-agnostic on purpose: the planner and collectives are tested on CPU tensors.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def plan_buckets(total: int, bucket_elems: int) -> List[Tuple[int, int]]:
+    """[lo, hi) slices covering [0,total) from the end, each ~bucket_elems (multiple of 4 elements)."""
+    bucket_elems = max(4, (bucket_elems // 4) * 4)
+    out = []
+    hi = total
+    while hi > 0:
+        lo = max(0, hi - bucket_elems)
+        lo -= lo % 4
+        out.append((lo, hi))
+        hi = lo
+    return out
+
+
+class GradBucketReducer:
+    """engine calls ready(low): every gradient at arena offset >= low is final.  Buckets whose
+    whole range is final are all-reduced asynchronously; finish() waits and averages."""
+
+    def __init__(self, flat_grad: torch.Tensor, group=None, bucket_mb: float = 64.0):
+        self.flat = flat_grad
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.buckets = plan_buckets(flat_grad.numel(), int(bucket_mb * (1 << 20) / 4))
+        self._next = 0
+        self._works = []
+        backend = dist.get_backend(group) if dist.is_initialized() else "none"
+        self._avg = backend == "nccl"
+        self.launched: List[Tuple[int, int]] = []
+
+    def begin(self):
+        self._next = 0
+        self._works = []
+        self.launched = []
+
+    def ready(self, low: int):
+        if self.world == 1:
+            return
+        while self._next < len(self.buckets) and self.buckets[self._next][0] >= low:
+            lo, hi = self.buckets[self._next]
+            op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+            w = dist.all_reduce(self.flat[lo:hi], op=op, group=self.group, async_op=True)
+            self._works.append((w, lo, hi))
+            self.launched.append((lo, hi))
+            self._next += 1
+
+    def finish(self):
+        if self.world == 1:
+            return
+        self.ready(0)
+        for w, lo, hi in self._works:
+            w.wait()
+            if not self._avg:
+                self.flat[lo:hi].mul_(1.0 / self.world)
+        self._works = []
+
+
+def broadcast_params(flat: torch.Tensor, src: int = 0, group=None):
+    """initial replica sync (DDP does this at wrap time) and re-sync after an intervention
+    (fixes the reference's rank-0-only nudge divergence)."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(flat, src=src, group=group)
+
+
+def allreduce_mean_(t: torch.Tensor, group=None) -> torch.Tensor:
+    """coalesced logging scalars / tracker vectors (train.py:292-294 uses 3 gathers + 3 .item())."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        t.mul_(1.0 / dist.get_world_size(group))
+    return t

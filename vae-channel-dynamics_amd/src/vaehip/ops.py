@@ -17,6 +17,56 @@ GN_GROUPS = 32
 GN_EPS = 1e-6
 
 
+class LaunchProfiler:
+    """optional HIP-event timing of the contraction kernels, per template instantiation
+    (used by bench.py for the live roofline figure; events go on the launch stream)."""
+
+    def __init__(self):
+        self.records = []  # (key, flops, start_event, end_event)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for key, flops, e0, e1 in self.records:
+            d = out.setdefault(key, {"launches": 0, "flops": 0.0, "ms": 0.0})
+            d["launches"] += 1
+            d["flops"] += flops
+            d["ms"] += e0.elapsed_time(e1)
+        return out
+
+
+PROFILER: Optional[LaunchProfiler] = None
+
+
+def _launch_igemm(a: IgemmArgs):
+    if PROFILER is None:
+        lib.call("vae_igemm_rows", C.byref(a), _stream())
+        return
+    bkm = int(a.sn == 1 and a.sk != 1)
+    vec = int(a.g.Cs % 4 == 0 and a.K % 4 == 0 and a.st % 4 == 0 and (a.sn % 4 == 0 if not bkm else (a.sk % 4 == 0 and a.N % 4 == 0)))
+    bn = 32 if a.N <= 32 else 128
+    key = f"igemm_rows_kernel<128,{bn},{4 if bn == 32 else 2},{1 if bn == 32 else 2},{'true' if bkm else 'false'},{'true' if vec else 'false'},{a.xf}>"
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    lib.call("vae_igemm_rows", C.byref(a), _stream())
+    e1.record()
+    PROFILER.records.append((key, 2.0 * a.M * a.N * a.K * a.g.taps * a.batch, e0, e1))
+
+
+def _launch_wgrad(a: WgradArgs):
+    if PROFILER is None:
+        lib.call("vae_wgrad", C.byref(a), _stream())
+        return
+    vec = int(a.g.Cs % 4 == 0 and a.ldy % 4 == 0 and a.M % 4 == 0 and a.N % 4 == 0)
+    tile = "32,128,1,4" if a.M <= 32 else ("128,32,4,1" if a.N <= 32 else "128,128,2,2")
+    key = f"wgrad_kernel<{tile},{'true' if vec else 'false'},{a.xf}>"
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    lib.call("vae_wgrad", C.byref(a), _stream())
+    e1.record()
+    PROFILER.records.append((key, 2.0 * a.M * a.N * a.npix * a.g.taps * a.batch, e0, e1))
+
+
 def _p(t: Optional[torch.Tensor]):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -106,7 +156,7 @@ def conv_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], kin
     a.xf, a.alpha = xf, 1.0
     if track is not None:
         assert track.numel() >= ((a.M + 127) // 128) * Co
-    lib.call("vae_igemm_rows", C.byref(a), _stream())
+    _launch_igemm(a)
     return out
 
 
@@ -136,7 +186,7 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, kind: str, in_hw: Tuple[int, i
     a.sn, a.sk, a.st = 1, taps * Ci, Ci
     a.batch, a.sAb, a.sWb, a.sCb = 1, 0, 0, 0
     a.xf, a.alpha = XF_NONE, 1.0
-    lib.call("vae_igemm_rows", C.byref(a), _stream())
+    _launch_igemm(a)
     if kind == "c3up":
         pooled = torch.empty((B, H, W, Ci), device=dy.device, dtype=torch.float32)
         lib.call("vae_sumpool2x2", _p(out), B, H, W, Ci, _p(pooled), _stream())
@@ -177,7 +227,7 @@ def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, kind: str, wgrad_out: torch.Te
     a.M, a.N, a.ldy, a.npix, a.nsplit = Co, Ci, Co, npix, ns
     a.batch, a.sYb, a.sXb, a.sOb = 1, 0, 0, 0
     a.xf, a.alpha = xf, 1.0
-    lib.call("vae_wgrad", C.byref(a), _stream())
+    _launch_wgrad(a)
     if partial is not None:
         lib.call("vae_reduce_splits", _p(partial), ns, Co * taps * Ci, _p(gv), _stream())
     if bgrad_out is not None:
@@ -273,7 +323,7 @@ def _gemm_rows(A, Bm, out, M, N, K, sn, sk, alpha, z, sAb, sWb, sCb):
     a.sn, a.sk, a.st = sn, sk, 0
     a.batch, a.sAb, a.sWb, a.sCb = z, sAb, sWb, sCb
     a.xf, a.alpha = XF_NONE, alpha
-    lib.call("vae_igemm_rows", C.byref(a), _stream())
+    _launch_igemm(a)
 
 
 def gemm_nt(A: torch.Tensor, Bm: torch.Tensor, alpha: float = 1.0) -> torch.Tensor:
@@ -305,7 +355,7 @@ def gemm_tn(A: torch.Tensor, Bm: torch.Tensor, alpha: float = 1.0) -> torch.Tens
     a.M, a.N, a.ldy, a.npix, a.nsplit = M, N, M, K, 1
     a.batch, a.sYb, a.sXb, a.sOb = z, K * M, K * N, M * N
     a.xf, a.alpha = XF_NONE, alpha
-    lib.call("vae_wgrad", C.byref(a), _stream())
+    _launch_wgrad(a)
     return out
 
 
