@@ -76,6 +76,11 @@ typedef struct vae_igemm_args {
   float alpha;           /* C = alpha * acc (+bias+res); 1.0 for conv             */
 } vae_igemm_args;
 int vae_igemm_rows(const vae_igemm_args* a, void* stream);
+/* 1 when xf != NONE can be fused for this geometry (the GroupNorm scale/shift rows a tile needs are staged in
+ * LDS once per workgroup); 0 => the caller materialises XF(x) with vae_gn_apply and passes xf = NONE.
+ * Only tiny spatial sizes (H*W < 128 with several batch items per tile) are not fusable.                  */
+int vae_xf_fusable_rows(const vae_conv_geom* g, int32_t M, int32_t K);
+int vae_xf_fusable_wgrad(const vae_conv_geom* g, int32_t npix, int32_t nsplit, int32_t N);
 
 /* dW[z][split][m][tap][n] = sum_{pix in split} dY[z][pix][m] * XF(X[z][row(pix,tap)][n])
  * replaces: conv2d wgrad, linear wgrad, attention P^T.dO and dS^T.Q (K7).
@@ -83,6 +88,7 @@ int vae_igemm_rows(const vae_igemm_args* a, void* stream);
  * `partial` ([nsplit][M][taps][N]) and the caller runs vae_reduce_splits.      */
 typedef struct vae_wgrad_args {
   const float* dY; const float* X; float* out; float* partial;
+  float* bias_partial;   /* optional [nsplit][M]: per-split column sums of dY (bias gradient); reduce like `partial` */
   const float* scale; const float* shift;
   vae_conv_geom g;       /* row grid = output pixels of the conv; source = X      */
   int32_t M, N;          /* M = Cout (cols of dY used), N = Cin (<= g.Cs)         */
@@ -124,8 +130,8 @@ int vae_gn_bwd_partial(const float* x, const float* g, const float* mean, const 
                        const float* gamma, const float* beta, int32_t B, int32_t HW, int32_t C, int32_t G,
                        int32_t nchunk, int32_t silu, float* ws, void* stream);
 /* stage 2: dgamma/dbeta [C] (written, not accumulated) and coefficients
- * coef [B][G][2] = {rstd*s2/N, rstd*s1/N}                                           */
-int vae_gn_bwd_final(const float* ws, const float* rstd, const float* gamma, int32_t B, int32_t HW,
+ * coef [B][G][2] = {rstd*s2/N, rstd*s1/N}; ws[b][0][c][:] is overwritten with the per-(b,c) totals                                        */
+int vae_gn_bwd_final(float* ws, const float* rstd, const float* gamma, int32_t B, int32_t HW,
                      int32_t C, int32_t G, int32_t nchunk, float* dgamma, float* dbeta, float* coef,
                      void* stream);
 /* stage 3: dx = du*rstd*gamma - xhat*coef0 - coef1 (+ add)                          */

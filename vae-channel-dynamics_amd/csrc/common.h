@@ -31,11 +31,11 @@ void vae_set_error(const char* fmt, ...);
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
 __device__ __forceinline__ float silu_f(float u) {
-  // u * sigmoid(u); v_exp_f32 + v_rcp_f32, ~1e-7 relative
-  return u * __frcp_rn(1.0f + __expf(-u));
+  // u * sigmoid(u); v_exp_f32 + v_rcp_f32 (1 ulp), ~1e-7 relative; __frcp_rn would expand to a full IEEE division
+  return u * __builtin_amdgcn_rcpf(1.0f + __expf(-u));
 }
 __device__ __forceinline__ float silu_grad_f(float u) {
-  float s = __frcp_rn(1.0f + __expf(-u));
+  float s = __builtin_amdgcn_rcpf(1.0f + __expf(-u));
   return s * (1.0f + u * (1.0f - s));
 }
 

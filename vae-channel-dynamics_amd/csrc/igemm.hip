@@ -15,6 +15,7 @@
 // GroupNorm+SiLU is applied to the A operand in that write pass, so the normalised
 // activation never exists in HBM.
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -33,39 +34,80 @@ __device__ __forceinline__ f32x4 load4(const float* p, int c, int C) {
   return v;
 }
 
-template <bool VEC, int XF>
-__device__ __forceinline__ f32x4 xform4(f32x4 v, const float* scale, const float* shift, int c, int C) {
-  if (XF == VAE_XF_NONE) return v;
-  f32x4 sc = load4<VEC>(scale, c, C);
-  f32x4 sh = load4<VEC>(shift, c, C);
+// Branch-free guarded load: an invalid lane reads the (always mapped, 16-B aligned) `safe` address and the
+// value is zeroed afterwards.  A per-lane `if (ok) load` makes hipcc wrap every load in an exec-mask branch
+// and wait for it separately (cdna_hip_programming.md, "Three .s-level traps" (c)).
+template <bool VEC>
+__device__ __forceinline__ f32x4 load4g(const float* p, bool ok, const float* safe, int c, int C) {
+  if (VEC) {
+    ok = ok && (c < C);
+    const float* q = ok ? p : safe;
+    f32x4 v = *reinterpret_cast<const f32x4*>(q);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
+    return v;
+  } else {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (ok) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (c + e < C) v[e] = p[e];
+    }
+    return v;
+  }
+}
+
+// LDS-table variant: no bounds branches (table entries beyond the valid columns are zero-filled)
+template <int XF>
+__device__ __forceinline__ f32x4 xform4_tab(f32x4 v, const float* scale, const float* shift, bool ok) {
+  f32x4 sc = *reinterpret_cast<const f32x4*>(scale);
+  f32x4 sh = *reinterpret_cast<const f32x4*>(shift);
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     float u = v[e] * sc[e] + sh[e];
     if (XF == VAE_XF_AFFINE_SILU) u = silu_f(u);
-    v[e] = (c + e < C) ? u : 0.f;
+    v[e] = ok ? u : 0.f;
   }
   return v;
 }
 
 // ---------------------------------------------------------------------------------------
-// rows kernel
+// rows kernel.  Pipeline: LDS is double buffered; the global loads of K-step s+2 are issued and
+// the registers of step s+1 are transformed + written to the other LDS stage in the MIDDLE of
+// step s's MFMA block, so one workgroup barrier per K-step suffices and the VALU/LDS-write work
+// sits in the shadow of MFMAs already issued.  The GroupNorm scale/shift rows the tile needs are
+// staged in LDS once per workgroup (they used to be 8 dependent global loads per thread per step).
 // ---------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, bool BKM, bool VEC, int XF>
-__global__ __launch_bounds__(256) void igemm_rows_kernel(vae_igemm_args p) {
+constexpr int SS_HALF = 512;  // floats of scale (and of shift) kept in LDS per workgroup
+
+// WS = wave-specialised variant: waves [0, WM*WN) only read fragments + issue MFMAs (consumers), waves
+// [WM*WN, 2*WM*WN) only stage tiles (producers: global loads, GroupNorm+SiLU, LDS writes).  Measured on MI355X
+// (tools/microbench.py, 512->512 @64^2 and 128->128 @256^2, B=16): 0...-8 % against the unified 8-wave
+// 128x128 workgroup (<128,128,4,2,false>), which is therefore the one dispatched; WS stays selectable for
+// re-measurement on other tile shapes.
+template <int BM, int BN, int WM, int WN, bool WS, bool BKM, bool VEC, int XF>
+__global__ __launch_bounds__((WS ? 128 : 64) * WM * WN) void igemm_rows_kernel(vae_igemm_args p) {
+  constexpr int NL = 64 * WM * WN;      // loader threads (== consumer threads)
+  constexpr int NT = WS ? 2 * NL : NL;  // workgroup size
+  constexpr int RP = NL / 8;            // tile rows covered by one pass of the float4 loaders
   constexpr int LDA = BK + 4;
   constexpr int LDB = BKM ? (BN + 4) : (BK + 4);
   constexpr int SA = BM * LDA;
   constexpr int SB = BKM ? BK * LDB : BN * LDB;
+  constexpr int STAGE = SA + SB;
+  constexpr int SS = (XF != VAE_XF_NONE) ? 2 * SS_HALF : 0;
   constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
-  constexpr int AR = BM / 32;                       // A rows per thread
-  constexpr int BR = BKM ? (BK / (256 / (BN / 4))) : (BN / 32);
-  static_assert(WM * WN == 4, "4 waves");
-  __shared__ __attribute__((aligned(16))) float smem[SA + SB];
-  float* sA = smem;
-  float* sB = smem + SA;
+  constexpr int AR = BM / RP;                       // A rows per thread
+  constexpr int BR = BKM ? (BK / (NL / (BN / 4))) : (BN / RP);
+  static_assert(AR >= 1 && BR >= 1 && TM % 32 == 0 && TN % 32 == 0, "tile/wave layout");
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE + SS];
+  float* sS = smem + 2 * STAGE;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
+  const bool prod = !WS || tid >= NL;  // wave-uniform roles
+  const bool cons = !WS || tid < NL;
+  const int lt = WS ? (tid & (NL - 1)) : tid;  // loader-thread index
+  const int wm = (wave % (WM * WN)) / WN, wn = wave % WN;
   const int tilesN = (p.N + BN - 1) / BN;
   const int tm = blockIdx.x / tilesN, tn = blockIdx.x % tilesN;
   const int m0 = tm * BM, n0 = tn * BN;
@@ -73,22 +115,33 @@ __global__ __launch_bounds__(256) void igemm_rows_kernel(vae_igemm_args p) {
   const vae_conv_geom g = p.g;
   const float* __restrict__ A = p.A + (int64_t)z * p.sAb;
   const float* __restrict__ W = p.W + (int64_t)z * p.sWb;
+  const int hw = g.Ho * g.Wo;
 
   // per-thread A rows
-  const int k4 = tid & 7, r0 = tid >> 3;
+  const int k4 = lt & 7, r0 = lt >> 3;
   int rb[AR], ry[AR], rx[AR];
-  {
-    const int hw = g.Ho * g.Wo;
 #pragma unroll
-    for (int i = 0; i < AR; ++i) {
-      int m = m0 + r0 + 32 * i;
-      if (m < p.M) {
-        int b = m / hw, rem = m - b * hw;
-        int y = rem / g.Wo;
-        rb[i] = b; ry[i] = y; rx[i] = rem - y * g.Wo;
-      } else {
-        rb[i] = -1; ry[i] = 0; rx[i] = 0;
-      }
+  for (int i = 0; i < AR; ++i) {
+    int m = m0 + r0 + RP * i;
+    if (m < p.M) {
+      int b = m / hw, rem = m - b * hw;
+      int y = rem / g.Wo;
+      rb[i] = b; ry[i] = y; rx[i] = rem - y * g.Wo;
+    } else {
+      rb[i] = -1; ry[i] = 0; rx[i] = 0;
+    }
+  }
+
+  // scale/shift table for the batches this tile touches
+  // (the host checks with vae_xf_fusable_rows that the rows of one tile never need more than SS_HALF entries)
+  const int b_lo = m0 / hw;
+  if (XF != VAE_XF_NONE) {
+    const int b_hi = (min(p.M, m0 + BM) - 1) / hw;
+    const int nent = min((b_hi - b_lo + 1) * p.K, SS_HALF);
+    for (int i = tid; i < nent; i += NT) {
+      const int j = i / p.K, c = i - j * p.K;
+      sS[i] = p.scale[(int64_t)(b_lo + j) * g.Cs + c];
+      sS[SS_HALF + i] = p.shift[(int64_t)(b_lo + j) * g.Cs + c];
     }
   }
 
@@ -105,103 +158,135 @@ __global__ __launch_bounds__(256) void igemm_rows_kernel(vae_igemm_args p) {
 
   f32x4 ra[AR], rbw[BR];
   int a_b[AR];  // batch index of the loaded row (for scale/shift), -1 = padding
-  int cur_c0 = 0;
+  int reg_c0 = 0;
 
   auto load_regs = [&](int s) {
     const int tap = s / kchunks;
     const int c0 = (s - tap * kchunks) * BK;
-    cur_c0 = c0;
+    reg_c0 = c0;
     const int kh = (g.taps == 9) ? tap / 3 : 0, kw = (g.taps == 9) ? tap - kh * 3 : 0;
     const int c = c0 + k4 * 4;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      a_b[i] = -1;
-      if (rb[i] >= 0) {
-        int sy, sx;
-        if (src_pixel(g, ry[i], rx[i], kh, kw, sy, sx)) {
-          const float* src = A + (((int64_t)rb[i] * g.Hs + sy) * g.Ws + sx) * g.Cs + c;
-          v = load4<VEC>(src, c, p.K);
-          a_b[i] = rb[i];
-        }
-      }
-      ra[i] = v;
+      int sy = 0, sx = 0;
+      const bool ok = src_pixel(g, ry[i], rx[i], kh, kw, sy, sx) && (rb[i] >= 0);
+      const float* src = A + (((int64_t)rb[i] * g.Hs + sy) * g.Ws + sx) * g.Cs + c;
+      ra[i] = load4g<VEC>(src, ok, A, c, p.K);
+      a_b[i] = ok ? rb[i] : -1;
     }
     if (!BKM) {
 #pragma unroll
       for (int i = 0; i < BR; ++i) {
-        int n = n0 + r0 + 32 * i;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (n < p.N) v = load4<VEC>(W + (int64_t)n * p.sn + (int64_t)tap * p.st + c, c, p.K);
-        rbw[i] = v;
+        const int n = n0 + r0 + RP * i;
+        rbw[i] = load4g<VEC>(W + (int64_t)n * p.sn + (int64_t)tap * p.st + c, n < p.N, W, c, p.K);
       }
     } else {
-      constexpr int NQ = BN / 4, KR = 256 / NQ;
-      const int n4 = tid % NQ, kq = tid / NQ;
+      constexpr int NQ = BN / 4, KR = NL / NQ;
+      const int n4 = lt % NQ, kq = lt / NQ;
 #pragma unroll
       for (int i = 0; i < BR; ++i) {
-        int k = c0 + kq + KR * i;
-        int n = n0 + n4 * 4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (k < p.K) v = load4<VEC>(W + (int64_t)k * p.sk + (int64_t)tap * p.st + n, n, p.N);
-        rbw[i] = v;
+        const int k = c0 + kq + KR * i;
+        const int n = n0 + n4 * 4;
+        rbw[i] = load4g<VEC>(W + (int64_t)k * p.sk + (int64_t)tap * p.st + n, k < p.K, W, n, p.N);
       }
     }
   };
 
-  auto store_lds = [&]() {
-    const int c = cur_c0 + k4 * 4;
+  auto store_lds = [&](float* sA, float* sB) {
+    const int c = reg_c0 + k4 * 4;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       f32x4 v = ra[i];
       if (XF != VAE_XF_NONE) {
-        if (a_b[i] >= 0) {
-          int64_t o = (int64_t)a_b[i] * g.Cs + c;
-          v = xform4<VEC, XF>(v, p.scale + o, p.shift + o, c, p.K);
-        }
+        const bool ok = (a_b[i] >= 0) && (c < p.K);
+        const int o = ok ? (a_b[i] - b_lo) * p.K + c : 0;
+        v = xform4_tab<XF>(v, sS + o, sS + SS_HALF + o, ok);
       }
-      *reinterpret_cast<f32x4*>(&sA[(r0 + 32 * i) * LDA + k4 * 4]) = v;
+      *reinterpret_cast<f32x4*>(&sA[(r0 + RP * i) * LDA + k4 * 4]) = v;
     }
     if (!BKM) {
 #pragma unroll
-      for (int i = 0; i < BR; ++i) *reinterpret_cast<f32x4*>(&sB[(r0 + 32 * i) * LDB + k4 * 4]) = rbw[i];
+      for (int i = 0; i < BR; ++i) *reinterpret_cast<f32x4*>(&sB[(r0 + RP * i) * LDB + k4 * 4]) = rbw[i];
     } else {
-      constexpr int NQ = BN / 4, KR = 256 / NQ;
-      const int n4 = tid % NQ, kq = tid / NQ;
+      constexpr int NQ = BN / 4, KR = NL / NQ;
+      const int n4 = lt % NQ, kq = lt / NQ;
 #pragma unroll
       for (int i = 0; i < BR; ++i) *reinterpret_cast<f32x4*>(&sB[(kq + KR * i) * LDB + n4 * 4]) = rbw[i];
     }
   };
 
-  load_regs(0);
   const int lr = lane & 31, lh = lane >> 5;
-  for (int s = 0; s < steps; ++s) {
-    __syncthreads();
-    store_lds();
-    __syncthreads();
-    if (s + 1 < steps) load_regs(s + 1);
+  auto compute = [&](const float* sA, const float* sB, int kk) {
+    f32x4 a[MI], b[NI];
 #pragma unroll
-    for (int kk = 0; kk < BK / 8; ++kk) {
-      f32x4 a[MI], b[NI];
+    for (int mi = 0; mi < MI; ++mi)
+      a[mi] = *reinterpret_cast<const f32x4*>(&sA[(wm * TM + mi * 32 + lr) * LDA + kk * 8 + lh * 4]);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      if (!BKM) {
+        b[ni] = *reinterpret_cast<const f32x4*>(&sB[(wn * TN + ni * 32 + lr) * LDB + kk * 8 + lh * 4]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[ni][j] = sB[(kk * 8 + lh * 4 + j) * LDB + wn * TN + ni * 32 + lr];
+      }
+    }
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
-        a[mi] = *reinterpret_cast<const f32x4*>(&sA[(wm * TM + mi * 32 + lr) * LDA + kk * 8 + lh * 4]);
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        if (!BKM) {
-          b[ni] = *reinterpret_cast<const f32x4*>(&sB[(wn * TN + ni * 32 + lr) * LDB + kk * 8 + lh * 4]);
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) b[ni][j] = sB[(kk * 8 + lh * 4 + j) * LDB + wn * TN + ni * 32 + lr];
-        }
+        for (int ni = 0; ni < NI; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  if (!WS) {
+    load_regs(0);
+    __syncthreads();  // scale/shift table visible
+    store_lds(smem, smem + SA);
+    if (steps > 1) load_regs(1);
+    __syncthreads();
+    for (int s = 0; s < steps; ++s) {
+      const float* cA = smem + (s & 1) * STAGE;
+      const float* cB = cA + SA;
+      compute(cA, cB, 0);
+      compute(cA, cB, 1);
+      if (s + 1 < steps) {
+        float* nA = smem + ((s + 1) & 1) * STAGE;
+        store_lds(nA, nA + SA);
+        if (s + 2 < steps) load_regs(s + 2);
       }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
+      compute(cA, cB, 2);
+      compute(cA, cB, 3);
+      __syncthreads();
+    }
+  } else if (prod) {
+    // producer waves: every wave of the workgroup executes the same number of barriers (2 + steps)
+    load_regs(0);
+    __syncthreads();  // scale/shift table visible
+    store_lds(smem, smem + SA);
+    if (steps > 1) load_regs(1);
+    __syncthreads();
+    for (int s = 0; s < steps; ++s) {
+      if (s + 1 < steps) {
+        float* nA = smem + ((s + 1) & 1) * STAGE;
+        store_lds(nA, nA + SA);  // stage (s+1)&1 was last read in step s-1, which every consumer has left
+        if (s + 2 < steps) load_regs(s + 2);
+      }
+      __syncthreads();
+    }
+  } else {
+    __syncthreads();
+    __syncthreads();
+    for (int s = 0; s < steps; ++s) {
+      const float* cA = smem + (s & 1) * STAGE;
+      const float* cB = cA + SA;
+      compute(cA, cB, 0);
+      compute(cA, cB, 1);
+      compute(cA, cB, 2);
+      compute(cA, cB, 3);
+      __syncthreads();
     }
   }
 
@@ -221,7 +306,7 @@ __global__ __launch_bounds__(256) void igemm_rows_kernel(vae_igemm_args p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * TM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (colok && row < p.M) {
+        if (cons && colok && row < p.M) {
           float v = p.alpha * acc[mi][ni][r] + bv;
           const int64_t o = (int64_t)row * p.ldc + col;
           if (R) v += R[o];
@@ -232,12 +317,11 @@ __global__ __launch_bounds__(256) void igemm_rows_kernel(vae_igemm_args p) {
     }
   }
   if (p.track && z == 0) {
-    float* red = smem;  // [WM][BN]
-    __syncthreads();
+    float* red = smem;  // [WM][BN]; the last loop barrier already separated it from the MFMA reads
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
       float s2 = tsum[ni] + __shfl_xor(tsum[ni], 32, 64);
-      if (lh == 0) red[wm * BN + wn * TN + ni * 32 + lr] = s2;
+      if (cons && lh == 0) red[wm * BN + wn * TN + ni * 32 + lr] = s2;
     }
     __syncthreads();
     if (tid < BN) {
@@ -251,21 +335,29 @@ __global__ __launch_bounds__(256) void igemm_rows_kernel(vae_igemm_args p) {
 
 // ---------------------------------------------------------------------------------------
 // wgrad kernel: out[m][tap][n] = sum_pix dY[pix][m] * XF(X[src(pix,tap)][n])
+// Same double-buffered one-barrier pipeline.  The bias gradient (column sums of dY) is folded in:
+// workgroups with tn == 0 and tap == 0 add up the dY tiles they stage anyway.
 // ---------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, bool VEC, int XF>
-__global__ __launch_bounds__(256) void wgrad_kernel(vae_wgrad_args p) {
+template <int BM, int BN, int WM, int WN, bool WS, bool VEC, int XF>
+__global__ __launch_bounds__((WS ? 128 : 64) * WM * WN) void wgrad_kernel(vae_wgrad_args p) {
+  constexpr int NL = 64 * WM * WN;
+  constexpr int NT = WS ? 2 * NL : NL;
   constexpr int LDA = BM + 4, LDB = BN + 4;
   constexpr int SA = BK * LDA, SB = BK * LDB;
+  constexpr int STAGE = SA + SB;
+  constexpr int SS = (XF != VAE_XF_NONE) ? 2 * SS_HALF : 0;
   constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
-  constexpr int AQ = BM / 4, AKR = 256 / AQ, AI = BK / AKR;  // dY tile: AQ float4 per row
-  constexpr int BQ = BN / 4, BKR = 256 / BQ, BI = BK / BKR;
-  static_assert(WM * WN == 4, "4 waves");
-  __shared__ __attribute__((aligned(16))) float smem[SA + SB];
-  float* sA = smem;
-  float* sB = smem + SA;
+  constexpr int AQ = BM / 4, AKR = NL / AQ, AI = BK / AKR;  // dY tile: AQ float4 per row
+  constexpr int BQ = BN / 4, BKR = NL / BQ, BI = BK / BKR;
+  static_assert(AI >= 1 && BI >= 1 && TM % 32 == 0 && TN % 32 == 0, "tile/wave layout");
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE + SS];
+  float* sS = smem + 2 * STAGE;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
+  const bool prod = !WS || tid >= NL;
+  const bool cons = !WS || tid < NL;
+  const int lt = WS ? (tid & (NL - 1)) : tid;
+  const int wm = (wave % (WM * WN)) / WN, wn = wave % WN;
   const int tilesN = (p.N + BN - 1) / BN;
   const int tm = blockIdx.x / tilesN, tn = blockIdx.x % tilesN;
   const int m0 = tm * BM, n0 = tn * BN;
@@ -282,6 +374,21 @@ __global__ __launch_bounds__(256) void wgrad_kernel(vae_wgrad_args p) {
   const int pend = min(p.npix, pbeg + chunk);
   const int steps = (pend > pbeg) ? (pend - pbeg + BK - 1) / BK : 0;
   const int hw = g.Ho * g.Wo;
+  const bool do_bias = (p.bias_partial != nullptr) && tn == 0 && tap == 0 && z == 0;
+
+  // (the host checks with vae_xf_fusable_wgrad that one split never spans more than SS_HALF/BN batch items)
+  const int b_lo = pbeg / hw;
+  if (XF != VAE_XF_NONE && steps > 0) {
+    const int nb = (pend - 1) / hw - b_lo + 1;
+    const int ncol = min(BN, p.N - n0);
+    const int nent = min(nb * BN, SS_HALF);
+    for (int i = tid; i < nent; i += NT) {
+      const int j = i / BN, c = i - j * BN;
+      const bool ok = c < ncol;
+      sS[i] = ok ? p.scale[(int64_t)(b_lo + j) * g.Cs + n0 + c] : 0.f;
+      sS[SS_HALF + i] = ok ? p.shift[(int64_t)(b_lo + j) * g.Cs + n0 + c] : 0.f;
+    }
+  }
 
   f32x16 acc[MI][NI];
 #pragma unroll
@@ -291,81 +398,119 @@ __global__ __launch_bounds__(256) void wgrad_kernel(vae_wgrad_args p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-  const int a4 = tid % AQ, akq = tid / AQ;
-  const int b4 = tid % BQ, bkq = tid / BQ;
+  const int a4 = lt % AQ, akq = lt / AQ;
+  const int b4 = lt % BQ, bkq = lt / BQ;
   f32x4 ra[AI], rx[BI];
   int xb[BI];
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
 
   auto load_regs = [&](int s) {
     const int pb = pbeg + s * BK;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-      int pix = pb + akq + AKR * i;
-      int c = m0 + a4 * 4;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (pix < pend) v = load4<VEC>(dY + (int64_t)pix * p.ldy + c, c, p.M);
-      ra[i] = v;
+      const int pix = pb + akq + AKR * i;
+      const int c = m0 + a4 * 4;
+      ra[i] = load4g<VEC>(dY + (int64_t)pix * p.ldy + c, pix < pend, dY, c, p.M);
     }
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
-      int pix = pb + bkq + BKR * i;
-      int c = n0 + b4 * 4;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      xb[i] = -1;
-      if (pix < pend) {
-        int b = pix / hw, rem = pix - b * hw;
-        int y = rem / g.Wo, x = rem - y * g.Wo;
-        int sy, sx;
-        if (src_pixel(g, y, x, kh, kw, sy, sx)) {
-          v = load4<VEC>(X + (((int64_t)b * g.Hs + sy) * g.Ws + sx) * g.Cs + c, c, p.N);
-          xb[i] = b;
-        }
-      }
-      rx[i] = v;
+      const int pix = pb + bkq + BKR * i;
+      const int c = n0 + b4 * 4;
+      const int b = pix / hw, rem = pix - b * hw;
+      const int y = rem / g.Wo, x = rem - y * g.Wo;
+      int sy = 0, sx = 0;
+      const bool ok = src_pixel(g, y, x, kh, kw, sy, sx) && (pix < pend);
+      rx[i] = load4g<VEC>(X + (((int64_t)b * g.Hs + sy) * g.Ws + sx) * g.Cs + c, ok, X, c, p.N);
+      xb[i] = ok ? b : -1;
     }
   };
-  auto store_lds = [&]() {
+  auto store_lds = [&](float* sA, float* sB) {
 #pragma unroll
-    for (int i = 0; i < AI; ++i) *reinterpret_cast<f32x4*>(&sA[(akq + AKR * i) * LDA + a4 * 4]) = ra[i];
+    for (int i = 0; i < AI; ++i) {
+      *reinterpret_cast<f32x4*>(&sA[(akq + AKR * i) * LDA + a4 * 4]) = ra[i];
+      if (do_bias) bsum += ra[i];
+    }
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
       f32x4 v = rx[i];
       if (XF != VAE_XF_NONE) {
-        if (xb[i] >= 0) {
-          int c = n0 + b4 * 4;
-          int64_t o = (int64_t)xb[i] * g.Cs + c;
-          v = xform4<VEC, XF>(v, p.scale + o, p.shift + o, c, p.N);
-        }
+        const bool ok = xb[i] >= 0;
+        const int o = ok ? (xb[i] - b_lo) * BN + b4 * 4 : 0;
+        v = xform4_tab<XF>(v, sS + o, sS + SS_HALF + o, ok);
       }
       *reinterpret_cast<f32x4*>(&sB[(bkq + BKR * i) * LDB + b4 * 4]) = v;
     }
   };
 
   const int lr = lane & 31, lh = lane >> 5;
-  if (steps > 0) load_regs(0);
-  for (int s = 0; s < steps; ++s) {
-    __syncthreads();
-    store_lds();
-    __syncthreads();
-    if (s + 1 < steps) load_regs(s + 1);
+  auto compute = [&](const float* sA, const float* sB, int kk) {
+    f32x4 a[MI], b[NI];
 #pragma unroll
-    for (int kk = 0; kk < BK / 8; ++kk) {
-      f32x4 a[MI], b[NI];
+    for (int j = 0; j < 4; ++j) {
+      const int k = kk * 8 + lh * 4 + j;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int k = kk * 8 + lh * 4 + j;
+      for (int mi = 0; mi < MI; ++mi) a[mi][j] = sA[k * LDA + wm * TM + mi * 32 + lr];
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) a[mi][j] = sA[k * LDA + wm * TM + mi * 32 + lr];
+      for (int ni = 0; ni < NI; ++ni) b[ni][j] = sB[k * LDB + wn * TN + ni * 32 + lr];
+    }
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) b[ni][j] = sB[k * LDB + wn * TN + ni * 32 + lr];
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  if (steps > 0) {
+    if (!WS) {
+      load_regs(0);
+      __syncthreads();  // scale/shift table visible
+      store_lds(smem, smem + SA);
+      if (steps > 1) load_regs(1);
+      __syncthreads();
+      for (int s = 0; s < steps; ++s) {
+        const float* cA = smem + (s & 1) * STAGE;
+        const float* cB = cA + SA;
+        compute(cA, cB, 0);
+        compute(cA, cB, 1);
+        if (s + 1 < steps) {
+          float* nA = smem + ((s + 1) & 1) * STAGE;
+          store_lds(nA, nA + SA);
+          if (s + 2 < steps) load_regs(s + 2);
+        }
+        compute(cA, cB, 2);
+        compute(cA, cB, 3);
+        __syncthreads();
       }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
+    } else if (prod) {
+      load_regs(0);
+      __syncthreads();
+      store_lds(smem, smem + SA);
+      if (steps > 1) load_regs(1);
+      __syncthreads();
+      for (int s = 0; s < steps; ++s) {
+        if (s + 1 < steps) {
+          float* nA = smem + ((s + 1) & 1) * STAGE;
+          store_lds(nA, nA + SA);
+          if (s + 2 < steps) load_regs(s + 2);
+        }
+        __syncthreads();
+      }
+    } else {
+      __syncthreads();
+      __syncthreads();
+      for (int s = 0; s < steps; ++s) {
+        const float* cA = smem + (s & 1) * STAGE;
+        const float* cB = cA + SA;
+        compute(cA, cB, 0);
+        compute(cA, cB, 1);
+        compute(cA, cB, 2);
+        compute(cA, cB, 3);
+        __syncthreads();
+      }
     }
   }
 
@@ -380,8 +525,22 @@ __global__ __launch_bounds__(256) void wgrad_kernel(vae_wgrad_args p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * TM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row < p.M) O[(int64_t)row * ld + (int64_t)tap * p.N + col] = p.alpha * acc[mi][ni][r];
+        if (cons && row < p.M) O[(int64_t)row * ld + (int64_t)tap * p.N + col] = p.alpha * acc[mi][ni][r];
       }
+  }
+  if (do_bias) {  // uniform per workgroup
+    f32x4* red = reinterpret_cast<f32x4*>(smem);  // [AKR][AQ]
+    if (prod) red[akq * AQ + a4] = bsum;
+    __syncthreads();
+    if (tid < AQ) {
+      f32x4 t = {0.f, 0.f, 0.f, 0.f};
+      for (int r = 0; r < AKR; ++r) t += red[r * AQ + tid];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = m0 + tid * 4 + e;
+        if (m < p.M) p.bias_partial[(int64_t)split * p.M + m] = t[e];
+      }
+    }
   }
 }
 
@@ -395,43 +554,43 @@ __global__ void reduce_splits_kernel(const float* __restrict__ partial, int nspl
   }
 }
 
-template <int BM, int BN, int WM, int WN, bool BKM, bool VEC>
+template <int BM, int BN, int WM, int WN, bool WS, bool BKM, bool VEC>
 int launch_rows_xf(const vae_igemm_args& a, dim3 grid, hipStream_t st) {
   if (BKM) {
     if (a.xf != VAE_XF_NONE) { vae_set_error("igemm_rows: xf unsupported with n-contiguous weights"); return VAE_EINVAL; }
-    hipLaunchKernelGGL((igemm_rows_kernel<BM, BN, WM, WN, BKM, VEC, VAE_XF_NONE>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((igemm_rows_kernel<BM, BN, WM, WN, WS, BKM, VEC, VAE_XF_NONE>), grid, dim3((WS ? 128 : 64) * WM * WN), 0, st, a);
     return 0;
   }
   switch (a.xf) {
-    case VAE_XF_NONE: hipLaunchKernelGGL((igemm_rows_kernel<BM, BN, WM, WN, false, VEC, VAE_XF_NONE>), grid, dim3(256), 0, st, a); break;
-    case VAE_XF_AFFINE: hipLaunchKernelGGL((igemm_rows_kernel<BM, BN, WM, WN, false, VEC, VAE_XF_AFFINE>), grid, dim3(256), 0, st, a); break;
-    case VAE_XF_AFFINE_SILU: hipLaunchKernelGGL((igemm_rows_kernel<BM, BN, WM, WN, false, VEC, VAE_XF_AFFINE_SILU>), grid, dim3(256), 0, st, a); break;
+    case VAE_XF_NONE: hipLaunchKernelGGL((igemm_rows_kernel<BM, BN, WM, WN, WS, false, VEC, VAE_XF_NONE>), grid, dim3((WS ? 128 : 64) * WM * WN), 0, st, a); break;
+    case VAE_XF_AFFINE: hipLaunchKernelGGL((igemm_rows_kernel<BM, BN, WM, WN, WS, false, VEC, VAE_XF_AFFINE>), grid, dim3((WS ? 128 : 64) * WM * WN), 0, st, a); break;
+    case VAE_XF_AFFINE_SILU: hipLaunchKernelGGL((igemm_rows_kernel<BM, BN, WM, WN, WS, false, VEC, VAE_XF_AFFINE_SILU>), grid, dim3((WS ? 128 : 64) * WM * WN), 0, st, a); break;
     default: vae_set_error("igemm_rows: bad xf %d", a.xf); return VAE_EINVAL;
   }
   return 0;
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool WS>
 int launch_rows(const vae_igemm_args& a, bool bkm, bool vec, hipStream_t st) {
   dim3 grid((unsigned)(((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN)), 1, (unsigned)a.batch);
-  if (bkm) return vec ? launch_rows_xf<BM, BN, WM, WN, true, true>(a, grid, st) : launch_rows_xf<BM, BN, WM, WN, true, false>(a, grid, st);
-  return vec ? launch_rows_xf<BM, BN, WM, WN, false, true>(a, grid, st) : launch_rows_xf<BM, BN, WM, WN, false, false>(a, grid, st);
+  if (bkm) return vec ? launch_rows_xf<BM, BN, WM, WN, WS, true, true>(a, grid, st) : launch_rows_xf<BM, BN, WM, WN, WS, true, false>(a, grid, st);
+  return vec ? launch_rows_xf<BM, BN, WM, WN, WS, false, true>(a, grid, st) : launch_rows_xf<BM, BN, WM, WN, WS, false, false>(a, grid, st);
 }
 
-template <int BM, int BN, int WM, int WN, bool VEC>
+template <int BM, int BN, int WM, int WN, bool WS, bool VEC>
 int launch_wgrad_xf(const vae_wgrad_args& a, dim3 grid, hipStream_t st) {
   switch (a.xf) {
-    case VAE_XF_NONE: hipLaunchKernelGGL((wgrad_kernel<BM, BN, WM, WN, VEC, VAE_XF_NONE>), grid, dim3(256), 0, st, a); break;
-    case VAE_XF_AFFINE: hipLaunchKernelGGL((wgrad_kernel<BM, BN, WM, WN, VEC, VAE_XF_AFFINE>), grid, dim3(256), 0, st, a); break;
-    case VAE_XF_AFFINE_SILU: hipLaunchKernelGGL((wgrad_kernel<BM, BN, WM, WN, VEC, VAE_XF_AFFINE_SILU>), grid, dim3(256), 0, st, a); break;
+    case VAE_XF_NONE: hipLaunchKernelGGL((wgrad_kernel<BM, BN, WM, WN, WS, VEC, VAE_XF_NONE>), grid, dim3((WS ? 128 : 64) * WM * WN), 0, st, a); break;
+    case VAE_XF_AFFINE: hipLaunchKernelGGL((wgrad_kernel<BM, BN, WM, WN, WS, VEC, VAE_XF_AFFINE>), grid, dim3((WS ? 128 : 64) * WM * WN), 0, st, a); break;
+    case VAE_XF_AFFINE_SILU: hipLaunchKernelGGL((wgrad_kernel<BM, BN, WM, WN, WS, VEC, VAE_XF_AFFINE_SILU>), grid, dim3((WS ? 128 : 64) * WM * WN), 0, st, a); break;
     default: vae_set_error("wgrad: bad xf %d", a.xf); return VAE_EINVAL;
   }
   return 0;
 }
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool WS>
 int launch_wgrad(const vae_wgrad_args& a, bool vec, hipStream_t st) {
   dim3 grid((unsigned)(((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN)), (unsigned)(a.g.taps * a.nsplit), (unsigned)a.batch);
-  return vec ? launch_wgrad_xf<BM, BN, WM, WN, true>(a, grid, st) : launch_wgrad_xf<BM, BN, WM, WN, false>(a, grid, st);
+  return vec ? launch_wgrad_xf<BM, BN, WM, WN, WS, true>(a, grid, st) : launch_wgrad_xf<BM, BN, WM, WN, WS, false>(a, grid, st);
 }
 
 int check_geom(const char* who, const vae_conv_geom& g) {
@@ -445,6 +604,25 @@ int check_geom(const char* who, const vae_conv_geom& g) {
 
 }  // namespace
 
+// rows of one 128-row tile span at most nb batch items; the LDS table holds SS_HALF scale entries
+static bool xf_rows_ok(const vae_conv_geom& g, int M, int K) {
+  const int hw = g.Ho * g.Wo;
+  const int nb = (hw % 128 == 0) ? 1 : (127 / hw + 2);
+  return (K % 4 == 0) && ((int64_t)std::min(nb, g.B) * K <= SS_HALF);
+}
+static bool xf_wgrad_ok(const vae_conv_geom& g, int npix, int nsplit, int N) {
+  const int hw = g.Ho * g.Wo;
+  int chunk = (npix + nsplit - 1) / nsplit;
+  chunk = ((chunk + BK - 1) / BK) * BK;
+  const int nb = (hw % chunk == 0) ? 1 : ((chunk - 1) / hw + 2);
+  const int bn = 128;  // conservative: the widest N tile any instantiation uses
+  return (N % 4 == 0) && ((int64_t)std::min(nb, g.B) * bn <= SS_HALF);
+}
+extern "C" int vae_xf_fusable_rows(const vae_conv_geom* g, int32_t M, int32_t K) { return g && xf_rows_ok(*g, M, K) ? 1 : 0; }
+extern "C" int vae_xf_fusable_wgrad(const vae_conv_geom* g, int32_t npix, int32_t nsplit, int32_t N) {
+  return g && xf_wgrad_ok(*g, npix, nsplit, N) ? 1 : 0;
+}
+
 extern "C" int vae_igemm_rows(const vae_igemm_args* ap, void* stream) {
   VAE_CHECK(ap != nullptr, "igemm_rows: null args");
   const vae_igemm_args& a = *ap;
@@ -457,6 +635,8 @@ extern "C" int vae_igemm_rows(const vae_igemm_args* ap, void* stream) {
   VAE_CHECK(a.sk == 1 || a.sn == 1, "igemm_rows: one of sn, sk must be 1 (sn=%lld sk=%lld)", (long long)a.sn,
             (long long)a.sk);
   VAE_CHECK(a.xf == VAE_XF_NONE || (a.scale && a.shift), "igemm_rows: xf needs scale/shift");
+  VAE_CHECK(a.xf == VAE_XF_NONE || xf_rows_ok(a.g, a.M, a.K),
+            "igemm_rows: fused GroupNorm needs the tile's scale/shift rows to fit LDS (see vae_xf_fusable_rows)");
   const bool bkm = (a.sn == 1) && (a.sk != 1);
   bool vec = aligned16(a.A) && aligned16(a.W) && (a.g.Cs % 4 == 0) && (a.K % 4 == 0) && (a.st % 4 == 0) &&
              (a.sAb % 4 == 0) && (a.sWb % 4 == 0);
@@ -464,7 +644,7 @@ extern "C" int vae_igemm_rows(const vae_igemm_args* ap, void* stream) {
   else vec = vec && (a.sn % 4 == 0);
   if (a.xf != VAE_XF_NONE) vec = vec && aligned16(a.scale) && aligned16(a.shift);
   hipStream_t st = (hipStream_t)stream;
-  int rc = (a.N <= 32) ? launch_rows<128, 32, 4, 1>(a, bkm, vec, st) : launch_rows<128, 128, 2, 2>(a, bkm, vec, st);
+  int rc = (a.N <= 32) ? launch_rows<128, 32, 4, 1, false>(a, bkm, vec, st) : launch_rows<128, 128, 4, 2, false>(a, bkm, vec, st);
   if (rc) return rc;
   VAE_LAUNCH_CHECK("igemm_rows");
   return VAE_OK;
@@ -482,14 +662,17 @@ extern "C" int vae_wgrad(const vae_wgrad_args* ap, void* stream) {
   VAE_CHECK(a.g.mode != VAE_MODE_DGRAD, "wgrad: dgrad geometry not valid here");
   VAE_CHECK(a.nsplit == 1 ? a.out != nullptr : a.partial != nullptr, "wgrad: missing output buffer");
   VAE_CHECK(a.xf == VAE_XF_NONE || (a.scale && a.shift), "wgrad: xf needs scale/shift");
+  VAE_CHECK(a.bias_partial == nullptr || a.batch == 1, "wgrad: bias_partial is for batch == 1 only");
+  VAE_CHECK(a.xf == VAE_XF_NONE || xf_wgrad_ok(a.g, a.npix, a.nsplit, a.N),
+            "wgrad: fused GroupNorm needs the split's scale/shift rows to fit LDS (see vae_xf_fusable_wgrad)");
   bool vec = aligned16(a.dY) && aligned16(a.X) && (a.g.Cs % 4 == 0) && (a.ldy % 4 == 0) && (a.M % 4 == 0) &&
              (a.N % 4 == 0) && (a.sYb % 4 == 0) && (a.sXb % 4 == 0);
   if (a.xf != VAE_XF_NONE) vec = vec && aligned16(a.scale) && aligned16(a.shift);
   hipStream_t st = (hipStream_t)stream;
   int rc;
-  if (a.M <= 32) rc = launch_wgrad<32, 128, 1, 4>(a, vec, st);
-  else if (a.N <= 32) rc = launch_wgrad<128, 32, 4, 1>(a, vec, st);
-  else rc = launch_wgrad<128, 128, 2, 2>(a, vec, st);
+  if (a.M <= 32) rc = launch_wgrad<32, 128, 1, 4, false>(a, vec, st);
+  else if (a.N <= 32) rc = launch_wgrad<128, 32, 4, 1, false>(a, vec, st);
+  else rc = launch_wgrad<128, 128, 4, 2, false>(a, vec, st);
   if (rc) return rc;
   VAE_LAUNCH_CHECK("wgrad");
   return VAE_OK;

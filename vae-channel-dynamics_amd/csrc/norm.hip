@@ -138,11 +138,26 @@ __global__ __launch_bounds__(256) void gn_track_partial_kernel(const float* __re
 
 __global__ __launch_bounds__(256) void track_final_kernel(const float* __restrict__ ws, int rows, int C,
                                                           float inv_count, float* __restrict__ out) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0;
-  for (int r = 0; r < rows; ++r) s += (double)ws[(int64_t)r * C + c];
-  out[c] = (float)(s * (double)inv_count);
+  // one workgroup per 4 channels; thread t owns rows t, t+256, ... (fixed order), then a fixed LDS tree
+  __shared__ double red[256][4];
+  const int c0 = blockIdx.x * 4;
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int r = threadIdx.x; r < rows; r += 256) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (c0 + e < C) s[e] += (double)ws[(int64_t)r * C + c0 + e];
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[threadIdx.x][e] = s[e];
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[threadIdx.x][e] += red[threadIdx.x + o][e];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 4 && c0 + (int)threadIdx.x < C) out[c0 + threadIdx.x] = (float)(red[0][threadIdx.x] * (double)inv_count);
 }
 
 template <bool SILU>
@@ -194,53 +209,52 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __rest
   }
 }
 
-// blocks 0..B-1: coef for batch b; block B: dgamma/dbeta
-__global__ __launch_bounds__(256) void gn_bwd_final_kernel(const float* __restrict__ ws, const float* __restrict__ rstd,
-                                                           const float* __restrict__ gamma, int B, int HW, int C,
-                                                           int G, int nchunk, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, float* __restrict__ coef) {
-  __shared__ float sg1[512], sg2[512];
+// stage 2a: one workgroup per batch item: chunk totals per (b,c) (kept in ws[b][0][c][:]) and the group coefficients
+__global__ __launch_bounds__(256) void gn_bwd_final_kernel(float* __restrict__ ws, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, int HW, int C, int G,
+                                                           int nchunk, float* __restrict__ coef) {
+  __shared__ float sg1[1024], sg2[1024];
   const int cpg = C / G;
-  if ((int)blockIdx.x < B) {
-    const int b = blockIdx.x;
-    for (int c0 = 0; c0 < C; c0 += 512) {  // C <= 512 in practice; loop keeps it general
-      __syncthreads();
-      for (int c = c0 + threadIdx.x; c < min(C, c0 + 512); c += 256) {
-        double a1 = 0.0, a2 = 0.0;
-        for (int k = 0; k < nchunk; ++k) {
-          const float* o = ws + (((int64_t)b * nchunk + k) * C + c) * 2;
-          a1 += (double)o[0];
-          a2 += (double)o[1];
-        }
-        sg1[c - c0] = (float)(a1 * (double)gamma[c]);
-        sg2[c - c0] = (float)(a2 * (double)gamma[c]);
-      }
-      __syncthreads();
-      const int g0 = c0 / cpg, g1 = min(C, c0 + 512) / cpg;
-      for (int g = g0 + threadIdx.x; g < g1; g += 256) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int j = 0; j < cpg; ++j) {
-          s1 += (double)sg1[g * cpg + j - c0];
-          s2 += (double)sg2[g * cpg + j - c0];
-        }
-        const double n = (double)HW * (double)cpg;
-        const double r = (double)rstd[b * G + g];
-        coef[((int64_t)b * G + g) * 2 + 0] = (float)(r * s2 / n);
-        coef[((int64_t)b * G + g) * 2 + 1] = (float)(r * s1 / n);
-      }
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    double a1 = 0.0, a2 = 0.0;
+    for (int k = 0; k < nchunk; ++k) {
+      const float* o = ws + (((int64_t)b * nchunk + k) * C + c) * 2;
+      a1 += (double)o[0];
+      a2 += (double)o[1];
     }
-  } else {
-    for (int c = threadIdx.x; c < C; c += 256) {
-      double a1 = 0.0, a2 = 0.0;
-      for (int r = 0; r < B * nchunk; ++r) {
-        const float* o = ws + ((int64_t)r * C + c) * 2;
-        a1 += (double)o[0];
-        a2 += (double)o[1];
-      }
-      dbeta[c] = (float)a1;
-      dgamma[c] = (float)a2;
-    }
+    float* o0 = ws + (((int64_t)b * nchunk) * C + c) * 2;  // only this thread touches column c of batch b
+    o0[0] = (float)a1;
+    o0[1] = (float)a2;
+    sg1[c] = (float)(a1 * (double)gamma[c]);
+    sg2[c] = (float)(a2 * (double)gamma[c]);
   }
+  __syncthreads();
+  for (int g = threadIdx.x; g < G; g += 256) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int j = 0; j < cpg; ++j) {
+      s1 += (double)sg1[g * cpg + j];
+      s2 += (double)sg2[g * cpg + j];
+    }
+    const double n = (double)HW * (double)cpg;
+    const double r = (double)rstd[b * G + g];
+    coef[((int64_t)b * G + g) * 2 + 0] = (float)(r * s2 / n);
+    coef[((int64_t)b * G + g) * 2 + 1] = (float)(r * s1 / n);
+  }
+}
+// stage 2b: dgamma/dbeta = sum over the batch of the per-(b,c) totals
+__global__ __launch_bounds__(256) void gn_bwd_dparam_kernel(const float* __restrict__ ws, int B, int C, int nchunk,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double a1 = 0.0, a2 = 0.0;
+  for (int b = 0; b < B; ++b) {
+    const float* o = ws + (((int64_t)b * nchunk) * C + c) * 2;
+    a1 += (double)o[0];
+    a2 += (double)o[1];
+  }
+  dbeta[c] = (float)a1;
+  dgamma[c] = (float)a2;
 }
 
 template <bool SILU>
@@ -340,7 +354,7 @@ extern "C" int vae_gn_track_partial(const float* x, const float* scale, const fl
 
 extern "C" int vae_track_final(const float* ws, int32_t rows, int32_t C, float inv_count, float* out, void* stream) {
   VAE_CHECK(ws && out && rows > 0 && C > 0, "track_final: bad args");
-  hipLaunchKernelGGL(track_final_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, rows, C, inv_count, out);
+  hipLaunchKernelGGL(track_final_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, ws, rows, C, inv_count, out);
   VAE_LAUNCH_CHECK("track_final");
   return VAE_OK;
 }
@@ -361,12 +375,14 @@ extern "C" int vae_gn_bwd_partial(const float* x, const float* g, const float* m
   return VAE_OK;
 }
 
-extern "C" int vae_gn_bwd_final(const float* ws, const float* rstd, const float* gamma, int32_t B, int32_t HW, int32_t C,
+extern "C" int vae_gn_bwd_final(float* ws, const float* rstd, const float* gamma, int32_t B, int32_t HW, int32_t C,
                                 int32_t G, int32_t nchunk, float* dgamma, float* dbeta, float* coef, void* stream) {
   if (int e = check_gn("gn_bwd_final", B, HW, C, G, nchunk)) return e;
   VAE_CHECK(ws && rstd && gamma && dgamma && dbeta && coef, "gn_bwd_final: null pointer");
-  hipLaunchKernelGGL(gn_bwd_final_kernel, dim3(B + 1), dim3(256), 0, (hipStream_t)stream, ws, rstd, gamma, B, HW, C, G,
-                     nchunk, dgamma, dbeta, coef);
+  VAE_CHECK(C <= 1024, "gn_bwd_final: C > 1024");
+  hipLaunchKernelGGL(gn_bwd_final_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, ws, rstd, gamma, HW, C, G, nchunk, coef);
+  hipLaunchKernelGGL(gn_bwd_dparam_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, B, C, nchunk, dgamma,
+                     dbeta);
   VAE_LAUNCH_CHECK("gn_bwd_final");
   return VAE_OK;
 }

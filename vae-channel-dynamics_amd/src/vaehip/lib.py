@@ -30,7 +30,7 @@ class IgemmArgs(C.Structure):
 
 
 class WgradArgs(C.Structure):
-    _fields_ = [("dY", _fp), ("X", _fp), ("out", _fp), ("partial", _fp), ("scale", _fp), ("shift", _fp),
+    _fields_ = [("dY", _fp), ("X", _fp), ("out", _fp), ("partial", _fp), ("bias_partial", _fp), ("scale", _fp), ("shift", _fp),
                 ("g", ConvGeom), ("M", C.c_int32), ("N", C.c_int32), ("ldy", C.c_int32), ("npix", C.c_int32),
                 ("nsplit", C.c_int32), ("batch", C.c_int32), ("sYb", C.c_int64), ("sXb", C.c_int64),
                 ("sOb", C.c_int64), ("xf", C.c_int32), ("alpha", C.c_float)]
@@ -42,6 +42,8 @@ i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 SIGNATURES = {
     "vae_igemm_rows": [C.POINTER(IgemmArgs), vp],
     "vae_wgrad": [C.POINTER(WgradArgs), vp],
+    "vae_xf_fusable_rows": [C.POINTER(ConvGeom), i32, i32],
+    "vae_xf_fusable_wgrad": [C.POINTER(ConvGeom), i32, i32, i32],
     "vae_reduce_splits": [vp, i32, i64, vp, vp],
     "vae_colsum": [vp, i64, i32, vp, vp, vp],
     "vae_gn_stats_partial": [vp, i32, i32, i32, i32, i32, vp, vp],
@@ -98,6 +100,10 @@ class _Lib:
         rc = getattr(dll, name)(*args)
         if rc != 0:
             raise VaeHipError(f"{name} failed ({rc}): {dll.vae_last_error().decode()}")
+
+    def query(self, name, *args) -> int:
+        """functions that return a value instead of a status"""
+        return getattr(self.load(), name)(*args)
 
     def abi_version(self) -> int:
         return self.load().vae_abi_version()

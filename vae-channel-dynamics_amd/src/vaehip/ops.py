@@ -45,7 +45,7 @@ def _launch_igemm(a: IgemmArgs):
     bkm = int(a.sn == 1 and a.sk != 1)
     vec = int(a.g.Cs % 4 == 0 and a.K % 4 == 0 and a.st % 4 == 0 and (a.sn % 4 == 0 if not bkm else (a.sk % 4 == 0 and a.N % 4 == 0)))
     bn = 32 if a.N <= 32 else 128
-    key = f"igemm_rows_kernel<128,{bn},{4 if bn == 32 else 2},{1 if bn == 32 else 2},{'true' if bkm else 'false'},{'true' if vec else 'false'},{a.xf}>"
+    key = f"igemm_rows_kernel<128,{bn},4,{1 if bn == 32 else 2},false,{'true' if bkm else 'false'},{'true' if vec else 'false'},{a.xf}>"
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     lib.call("vae_igemm_rows", C.byref(a), _stream())
@@ -58,7 +58,7 @@ def _launch_wgrad(a: WgradArgs):
         lib.call("vae_wgrad", C.byref(a), _stream())
         return
     vec = int(a.g.Cs % 4 == 0 and a.ldy % 4 == 0 and a.M % 4 == 0 and a.N % 4 == 0)
-    tile = "32,128,1,4" if a.M <= 32 else ("128,32,4,1" if a.N <= 32 else "128,128,2,2")
+    tile = "32,128,1,4,false" if a.M <= 32 else ("128,32,4,1,false" if a.N <= 32 else "128,128,4,2,false")
     key = f"wgrad_kernel<{tile},{'true' if vec else 'false'},{a.xf}>"
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -139,6 +139,8 @@ def conv_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], kin
     taps = kh * kw
     assert taps == (1 if kind == "c1" else 9) and Ci <= Cs, (kind, wv.shape, x.shape)
     g = _fwd_geom(kind, B, H, W, Cs)
+    if xf != XF_NONE and not lib.query("vae_xf_fusable_rows", C.byref(g), B * g.Ho * g.Wo, Ci):
+        x, xf = gn_apply(x, stats, xf), XF_NONE  # tiny spatial size: several batch items per tile
     out = torch.empty((B, g.Ho, g.Wo, Co), device=x.device, dtype=torch.float32)
     if res is not None:
         _chk_c(res, "conv_fwd.res")
@@ -212,6 +214,8 @@ def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, kind: str, wgrad_out: torch.Te
     npix = B * g.Ho * g.Wo
     tiles = ((Co + 127) // 128) * ((Ci + 127) // 128) * taps
     ns = _nsplit(tiles, npix)
+    if xf != XF_NONE and not lib.query("vae_xf_fusable_wgrad", C.byref(g), npix, ns, Ci):
+        x, xf = gn_apply(x, stats, xf), XF_NONE
     a = WgradArgs()
     a.dY, a.X = _p(dy), _p(x)
     partial = None
@@ -220,6 +224,10 @@ def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, kind: str, wgrad_out: torch.Te
     else:
         partial = torch.empty((ns, Co * taps * Ci), device=x.device, dtype=torch.float32)
         a.partial = _p(partial)
+    bpart = None
+    if bgrad_out is not None:  # bias gradient = column sums of dY, folded into the wgrad kernel
+        bpart = torch.empty((ns, Co), device=x.device, dtype=torch.float32)
+        a.bias_partial = _p(bpart)
     if xf != XF_NONE:
         assert stats is not None
         a.scale, a.shift = _p(stats.scale), _p(stats.shift)
@@ -230,8 +238,8 @@ def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, kind: str, wgrad_out: torch.Te
     _launch_wgrad(a)
     if partial is not None:
         lib.call("vae_reduce_splits", _p(partial), ns, Co * taps * Ci, _p(gv), _stream())
-    if bgrad_out is not None:
-        colsum(dy.view(npix, Co), bgrad_out)
+    if bpart is not None:
+        lib.call("vae_reduce_splits", _p(bpart), ns, Co, _p(bgrad_out), _stream())
 
 
 def colsum(x2d: torch.Tensor, out: torch.Tensor):
