@@ -49,7 +49,9 @@ def cpu_baseline(max_seconds: float = 40.0):
     hooks = []
     for conf in TRACKING_CFG["target_layers"]:
         mod = o.get_submodule(conf["name"])
-        hooks.append(mod.register_forward_hook(lambda m, i, out: vo.mean_abs_per_channel(out)))
+        def hook(m, i, out):  # the reference's hook body (monitor.py:66-67); must return None
+            vo.mean_abs_per_channel(out)
+        hooks.append(mod.register_forward_hook(hook))
     tr = vo.OracleTrainer(o, max_steps=100)
     tr.step(vo.synthetic_pixels(1, 64, 1), vo.synthetic_eps(1, 64, 1))  # warm-up (library init)
     b = 1

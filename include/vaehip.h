@@ -80,7 +80,6 @@ int vae_igemm_rows(const vae_igemm_args* a, void* stream);
  * LDS once per workgroup); 0 => the caller materialises XF(x) with vae_gn_apply and passes xf = NONE.
  * Only tiny spatial sizes (H*W < 128 with several batch items per tile) are not fusable.                  */
 int vae_xf_fusable_rows(const vae_conv_geom* g, int32_t M, int32_t K);
-int vae_xf_fusable_wgrad(const vae_conv_geom* g, int32_t npix, int32_t nsplit, int32_t N);
 
 /* dW[z][split][m][tap][n] = sum_{pix in split} dY[z][pix][m] * XF(X[z][row(pix,tap)][n])
  * replaces: conv2d wgrad, linear wgrad, attention P^T.dO and dS^T.Q (K7).
@@ -100,6 +99,9 @@ typedef struct vae_wgrad_args {
   float alpha;
 } vae_wgrad_args;
 int vae_wgrad(const vae_wgrad_args* a, void* stream);
+/* split-K plan for `a` (a->nsplit ignored): the nsplit to launch with, and whether a->xf can be fused
+ * (0 => materialise XF(X) with vae_gn_apply and pass xf = NONE; only tiny spatial sizes).                */
+int vae_wgrad_plan(const vae_wgrad_args* a, int32_t* nsplit, int32_t* xf_fusable);
 /* out[i] = sum_s partial[s][i], fixed order (deterministic)                     */
 int vae_reduce_splits(const float* partial, int32_t nsplit, int64_t n, float* out, void* stream);
 /* colsum: out[c] = sum_rows X[r][c]  (conv / linear bias gradient) two-stage deterministic;

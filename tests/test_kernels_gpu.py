@@ -57,6 +57,12 @@ CONV_CASES = [
     ("c3s2", 1, 10, 14, 128, 128),
     ("c3up", 2, 8, 8, 128, 128),    # upsampler
     ("c3up", 1, 5, 6, 256, 256),
+    # shapes served by the LDS halo-tile kernel (W % 32 == 0, H % 4 == 0, Cout > 32)
+    ("c3", 2, 8, 32, 128, 128),
+    ("c3", 1, 4, 64, 256, 512),
+    ("c3", 2, 12, 32, 512, 256),
+    ("c3up", 2, 4, 16, 128, 256),
+    ("c3up", 1, 6, 32, 256, 256),
 ]
 
 
@@ -94,7 +100,8 @@ def test_conv_fwd_dgrad_wgrad(cuda, kind, B, H, W, Ci, Co):
     assert _rel(gb.cpu(), br.grad) < 3e-5
 
 
-@pytest.mark.parametrize("C,H,W,silu", [(128, 16, 16, True), (256, 8, 8, True), (512, 4, 4, True), (512, 6, 10, False)])
+@pytest.mark.parametrize("C,H,W,silu", [(128, 16, 16, True), (256, 8, 8, True), (512, 4, 4, True), (512, 6, 10, False),
+                                         (128, 8, 32, True), (512, 4, 32, True), (256, 4, 64, False)])  # last 3: halo-tile kernel
 def test_gn_fused_conv_and_backward(cuda, C, H, W, silu):
     """GroupNorm(+SiLU) fused into the conv operand load; GN backward; tracker reduction."""
     from vaehip import ops

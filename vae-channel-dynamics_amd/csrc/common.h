@@ -71,3 +71,59 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+
+// ---------------------------------------------------------------------------------------
+// operand staging helpers shared by the contraction kernels
+// ---------------------------------------------------------------------------------------
+constexpr int SS_HALF = 512;  // floats of GroupNorm scale (and of shift) kept in LDS per workgroup
+
+template <bool VEC>
+__device__ __forceinline__ f32x4 load4(const float* p, int c, int C) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (VEC) {
+    if (c < C) v = *reinterpret_cast<const f32x4*>(p);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (c + e < C) v[e] = p[e];
+  }
+  return v;
+}
+
+// Branch-free guarded load: an invalid lane reads the (always mapped, 16-B aligned) `safe` address and the
+// value is zeroed afterwards.  A per-lane `if (ok) load` makes hipcc wrap every load in an exec-mask branch
+// and wait for it separately (cdna_hip_programming.md, "Three .s-level traps" (c)).
+template <bool VEC>
+__device__ __forceinline__ f32x4 load4g(const float* p, bool ok, const float* safe, int c, int C) {
+  if (VEC) {
+    ok = ok && (c < C);
+    const float* q = ok ? p : safe;
+    f32x4 v = *reinterpret_cast<const f32x4*>(q);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
+    return v;
+  } else {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (ok) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (c + e < C) v[e] = p[e];
+    }
+    return v;
+  }
+}
+
+// LDS-table variant: no bounds branches (table entries beyond the valid columns are zero-filled)
+template <int XF>
+__device__ __forceinline__ f32x4 xform4_tab(f32x4 v, const float* scale, const float* shift, bool ok) {
+  f32x4 sc = *reinterpret_cast<const f32x4*>(scale);
+  f32x4 sh = *reinterpret_cast<const f32x4*>(shift);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float u = v[e] * sc[e] + sh[e];
+    if (XF == VAE_XF_AFFINE_SILU) u = silu_f(u);
+    v[e] = ok ? u : 0.f;
+  }
+  return v;
+}
+

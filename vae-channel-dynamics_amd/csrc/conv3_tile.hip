@@ -1,0 +1,257 @@
+// 3x3 stride-1 convolution (forward, forward over a virtual nearest-2x upsample, and dgrad) as a
+// direct convolution over an LDS-staged input HALO tile -- no im2col, and the nine filter taps share one
+// staged tile.
+//
+// Workgroup = 8 waves (512 threads) = one 4x32-pixel output tile x 128 output channels of one image.
+// Per 32-channel input chunk the (4+2)x(32+2)-pixel halo is staged ONCE (GroupNorm+SiLU applied in that
+// write pass, i.e. 1.6 transforms per input element instead of 9), then the 9 taps are 9 K-steps that only
+// re-stage the 128x32 weight tile (double buffered, one barrier per step) and read the SAME halo at a
+// shifted offset.  Wave (wm, wn) owns output row wm of the tile (32 consecutive pixels = one conflict-free
+// ds_read_b128 fragment per k-group) and 64 channels.  Compared with the flat implicit GEMM
+// (igemm.hip) this removes 8/9 of the activation loads, address arithmetic and transforms.
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 32, TH = 4, TW = 32, HW_ = TW + 2, HP = (TH + 2) * HW_;  // 204 halo pixels
+constexpr int LDA = BK + 4, BN = 128, NT = 512;
+constexpr int SH = HP * LDA;            // halo stage (floats)
+constexpr int HQ = HP * (BK / 4);       // float4 slots of the halo stage (1632)
+constexpr int HI = (HQ + NT - 1) / NT;  // halo float4 per thread (4)
+
+template <bool BKM, bool DG, bool UP, int XF>
+__global__ __launch_bounds__(NT) void conv3_tile_kernel(vae_igemm_args p, int tiles_x, int tiles_y) {
+  constexpr int LDB = BKM ? (BN + 4) : LDA;
+  constexpr int SB = BKM ? BK * LDB : BN * LDB;
+  constexpr int SS = (XF != VAE_XF_NONE) ? 2 * SS_HALF : 0;
+  constexpr int RP = NT / 8;                               // 64 weight rows per loader pass
+  constexpr int BR = BKM ? (BK / (NT / (BN / 4))) : (BN / RP);  // 2
+  __shared__ __attribute__((aligned(16))) float smem[SH + 2 * SB + SS];
+  float* sH = smem;
+  float* sBst = smem + SH;
+  float* sS = smem + SH + 2 * SB;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+  const vae_conv_geom g = p.g;
+  const int tilesN = (p.N + BN - 1) / BN;
+  int t = blockIdx.x;
+  const int tn = t % tilesN; t /= tilesN;
+  const int tx = t % tiles_x; t /= tiles_x;
+  const int ty = t % tiles_y;
+  const int b = t / tiles_y;
+  const int tile_lin = blockIdx.x / tilesN;
+  const int y0 = ty * TH, x0 = tx * TW, n0 = tn * BN;
+  const float* __restrict__ A = p.A;
+  const float* __restrict__ W = p.W;
+  const int Hb = UP ? 2 * g.Hs : g.Hs, Wb = UP ? 2 * g.Ws : g.Ws;  // bounds of the (virtual) source grid
+
+  if (XF != VAE_XF_NONE) {
+    for (int c = tid; c < p.K; c += NT) {  // K <= SS_HALF checked by the launcher; one image per tile
+      sS[c] = p.scale[(int64_t)b * g.Cs + c];
+      sS[SS_HALF + c] = p.shift[(int64_t)b * g.Cs + c];
+    }
+  }
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
+
+  const int kchunks = (p.K + BK - 1) / BK;
+  const int steps = 9 * kchunks;
+
+  // ---- halo staging: thread owns float4 slots q = tid + NT*i ----
+  f32x4 rh[HI];
+  int hmask = 0, hc0 = 0;
+  auto load_halo = [&](int c0) {
+    hc0 = c0;
+    hmask = 0;
+#pragma unroll
+    for (int i = 0; i < HI; ++i) {
+      const int q = tid + NT * i;
+      const int pp = q >> 3, k4 = q & 7;
+      const int ir = pp / HW_, jc = pp - ir * HW_;
+      const int hy = y0 - 1 + ir, hx = x0 - 1 + jc;
+      const int c = c0 + k4 * 4;
+      const bool ok = (q < HQ) && ((unsigned)hy < (unsigned)Hb) && ((unsigned)hx < (unsigned)Wb) && (c < p.K);
+      const int sy = UP ? (hy >> 1) : hy, sx = UP ? (hx >> 1) : hx;
+      rh[i] = load4g<true>(A + (((int64_t)b * g.Hs + sy) * g.Ws + sx) * g.Cs + c, ok, A, c, p.K);
+      hmask |= (ok ? 1 : 0) << i;
+    }
+  };
+  auto store_halo = [&]() {
+#pragma unroll
+    for (int i = 0; i < HI; ++i) {
+      const int q = tid + NT * i;
+      if (q < HQ) {
+        f32x4 v = rh[i];
+        if (XF != VAE_XF_NONE) {
+          const bool ok = (hmask >> i) & 1;
+          const int o = ok ? hc0 + (q & 7) * 4 : 0;
+          v = xform4_tab<XF>(v, sS + o, sS + SS_HALF + o, ok);
+        }
+        *reinterpret_cast<f32x4*>(&sH[(q >> 3) * LDA + (q & 7) * 4]) = v;
+      }
+    }
+  };
+
+  // ---- weight staging (same tile formats as igemm.hip) ----
+  f32x4 rw[BR];
+  const int k4w = tid & 7, r0w = tid >> 3;
+  auto load_w = [&](int s) {
+    const int cch = s / 9, tap = s - cch * 9;
+    const int c0 = cch * BK;
+    if (!BKM) {
+      const int c = c0 + k4w * 4;
+#pragma unroll
+      for (int i = 0; i < BR; ++i) {
+        const int n = n0 + r0w + RP * i;
+        rw[i] = load4g<true>(W + (int64_t)n * p.sn + (int64_t)tap * p.st + c, n < p.N, W, c, p.K);
+      }
+    } else {
+      constexpr int NQ = BN / 4, KR = NT / NQ;
+      const int n4 = tid % NQ, kq = tid / NQ;
+#pragma unroll
+      for (int i = 0; i < BR; ++i) {
+        const int k = c0 + kq + KR * i;
+        const int n = n0 + n4 * 4;
+        rw[i] = load4g<true>(W + (int64_t)k * p.sk + (int64_t)tap * p.st + n, k < p.K, W, n, p.N);
+      }
+    }
+  };
+  auto store_w = [&](float* sB) {
+    if (!BKM) {
+#pragma unroll
+      for (int i = 0; i < BR; ++i) *reinterpret_cast<f32x4*>(&sB[(r0w + RP * i) * LDB + k4w * 4]) = rw[i];
+    } else {
+      constexpr int NQ = BN / 4, KR = NT / NQ;
+      const int n4 = tid % NQ, kq = tid / NQ;
+#pragma unroll
+      for (int i = 0; i < BR; ++i) *reinterpret_cast<f32x4*>(&sB[(kq + KR * i) * LDB + n4 * 4]) = rw[i];
+    }
+  };
+
+  auto compute = [&](const float* sA, const float* sB, int kk) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(&sA[kk * 8 + lh * 4]);
+    f32x4 bq[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      if (!BKM) {
+        bq[ni] = *reinterpret_cast<const f32x4*>(&sB[(wn * 64 + ni * 32 + lr) * LDB + kk * 8 + lh * 4]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bq[ni][j] = sB[(kk * 8 + lh * 4 + j) * LDB + wn * 64 + ni * 32 + lr];
+      }
+    }
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bq[ni][j], acc[ni], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  load_halo(0);
+  load_w(0);
+  __syncthreads();  // scale/shift table visible
+  store_halo();
+  store_w(sBst);
+  if (steps > 1) load_w(1);
+  __syncthreads();
+  int cch = 0, tap = 0;
+  for (int s = 0; s < steps; ++s) {
+    const int kh = tap / 3, kw = tap - kh * 3;
+    const int dy = DG ? 2 - kh : kh, dx = DG ? 2 - kw : kw;
+    const float* cA = sH + ((wm + dy) * HW_ + lr + dx) * LDA;
+    const float* cB = sBst + (s & 1) * SB;
+    if (tap == 0 && cch + 1 < kchunks) load_halo((cch + 1) * BK);  // lands during this chunk's 9 taps
+    compute(cA, cB, 0);
+    compute(cA, cB, 1);
+    if (s + 1 < steps) {
+      store_w(sBst + ((s + 1) & 1) * SB);
+      if (s + 2 < steps) load_w(s + 2);
+    }
+    compute(cA, cB, 2);
+    compute(cA, cB, 3);
+    __syncthreads();
+    if (++tap == 9) {
+      tap = 0;
+      if (++cch < kchunks) {  // every wave has left the old halo (barrier above): restage it for the next chunk
+        store_halo();
+        __syncthreads();
+      }
+    }
+  }
+
+  // ---------------- epilogue ----------------
+  const int oy = y0 + wm;
+  float tsum[2] = {0.f, 0.f};
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int col = n0 + wn * 64 + ni * 32 + lr;
+    const bool colok = col < p.N;
+    const float bv = (p.bias && colok) ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ox = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (colok && oy < g.Ho && ox < g.Wo) {
+        const int64_t o = (((int64_t)b * g.Ho + oy) * g.Wo + ox) * p.ldc + col;
+        float v = p.alpha * acc[ni][r] + bv;
+        if (p.res) v += p.res[o];
+        p.C[o] = v;
+        tsum[ni] += fabsf(v);
+      }
+    }
+  }
+  if (p.track) {
+    float* red = smem;  // [4][BN]; the loop's last barrier separates this from the MFMA-phase reads
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const float s2 = tsum[ni] + __shfl_xor(tsum[ni], 32, 64);
+      if (lh == 0) red[wm * BN + wn * 64 + ni * 32 + lr] = s2;
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.N)
+      p.track[(int64_t)tile_lin * p.N + n0 + tid] = (red[tid] + red[BN + tid]) + (red[2 * BN + tid] + red[3 * BN + tid]);
+  }
+}
+
+template <bool BKM, bool DG, bool UP>
+void launch_xf(const vae_igemm_args& a, dim3 grid, int tx, int ty, hipStream_t st) {
+  switch (a.xf) {
+    case VAE_XF_NONE: hipLaunchKernelGGL((conv3_tile_kernel<BKM, DG, UP, VAE_XF_NONE>), grid, dim3(NT), 0, st, a, tx, ty); break;
+    case VAE_XF_AFFINE: hipLaunchKernelGGL((conv3_tile_kernel<BKM, DG, UP, VAE_XF_AFFINE>), grid, dim3(NT), 0, st, a, tx, ty); break;
+    default: hipLaunchKernelGGL((conv3_tile_kernel<BKM, DG, UP, VAE_XF_AFFINE_SILU>), grid, dim3(NT), 0, st, a, tx, ty); break;
+  }
+}
+
+}  // namespace
+
+// geometry this kernel covers; everything else stays on the flat implicit GEMM
+bool conv3_tile_eligible(const vae_igemm_args& a, bool vec, bool bkm) {
+  const vae_conv_geom& g = a.g;
+  if (!vec || a.batch != 1 || g.taps != 9 || g.stride != 1 || g.pad_t != 1 || g.pad_l != 1) return false;
+  if (a.N <= 32 || a.K % 4 != 0 || a.alpha != 1.0f) return false;
+  if (g.Wo % TW != 0 || g.Ho % TH != 0) return false;
+  if (a.xf != VAE_XF_NONE && (a.K > SS_HALF || bkm)) return false;
+  if (g.mode == VAE_MODE_FWD) return g.Ho == g.Hs && g.Wo == g.Ws && !bkm;
+  if (g.mode == VAE_MODE_UP2X) return g.Ho == 2 * g.Hs && g.Wo == 2 * g.Ws && !bkm;
+  if (g.mode == VAE_MODE_DGRAD) return g.Ho == g.Hs && g.Wo == g.Ws && bkm && a.xf == VAE_XF_NONE;
+  return false;
+}
+
+int launch_conv3_tile(const vae_igemm_args& a, bool bkm, hipStream_t st) {
+  const vae_conv_geom& g = a.g;
+  const int tx = g.Wo / TW, ty = g.Ho / TH;
+  const int64_t nblk = (int64_t)((a.N + BN - 1) / BN) * tx * ty * g.B;
+  if (nblk > 0x7fffffffLL) return VAE_EINVAL;
+  dim3 grid((unsigned)nblk);
+  if (g.mode == VAE_MODE_DGRAD) launch_xf<true, true, false>(a, grid, tx, ty, st);
+  else if (g.mode == VAE_MODE_UP2X) launch_xf<false, false, true>(a, grid, tx, ty, st);
+  else launch_xf<false, false, false>(a, grid, tx, ty, st);
+  return 0;
+}

@@ -16,60 +16,17 @@
 // activation never exists in HBM.
 #include "common.h"
 #include <algorithm>
+#include <stdlib.h>
+
+bool conv3_tile_eligible(const vae_igemm_args& a, bool vec, bool bkm);
+int launch_conv3_tile(const vae_igemm_args& a, bool bkm, hipStream_t st);
+bool wgrad3_tile_eligible(const vae_wgrad_args& a, bool vec);
+int64_t wgrad3_tile_units(const vae_conv_geom& g);
+int launch_wgrad3_tile(const vae_wgrad_args& a, hipStream_t st);
 
 namespace {
 
 constexpr int BK = 32;
-
-template <bool VEC>
-__device__ __forceinline__ f32x4 load4(const float* p, int c, int C) {
-  f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  if (VEC) {
-    if (c < C) v = *reinterpret_cast<const f32x4*>(p);
-  } else {
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (c + e < C) v[e] = p[e];
-  }
-  return v;
-}
-
-// Branch-free guarded load: an invalid lane reads the (always mapped, 16-B aligned) `safe` address and the
-// value is zeroed afterwards.  A per-lane `if (ok) load` makes hipcc wrap every load in an exec-mask branch
-// and wait for it separately (cdna_hip_programming.md, "Three .s-level traps" (c)).
-template <bool VEC>
-__device__ __forceinline__ f32x4 load4g(const float* p, bool ok, const float* safe, int c, int C) {
-  if (VEC) {
-    ok = ok && (c < C);
-    const float* q = ok ? p : safe;
-    f32x4 v = *reinterpret_cast<const f32x4*>(q);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
-    return v;
-  } else {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (ok) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (c + e < C) v[e] = p[e];
-    }
-    return v;
-  }
-}
-
-// LDS-table variant: no bounds branches (table entries beyond the valid columns are zero-filled)
-template <int XF>
-__device__ __forceinline__ f32x4 xform4_tab(f32x4 v, const float* scale, const float* shift, bool ok) {
-  f32x4 sc = *reinterpret_cast<const f32x4*>(scale);
-  f32x4 sh = *reinterpret_cast<const f32x4*>(shift);
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    float u = v[e] * sc[e] + sh[e];
-    if (XF == VAE_XF_AFFINE_SILU) u = silu_f(u);
-    v[e] = ok ? u : 0.f;
-  }
-  return v;
-}
 
 // ---------------------------------------------------------------------------------------
 // rows kernel.  Pipeline: LDS is double buffered; the global loads of K-step s+2 are issued and
@@ -78,7 +35,6 @@ __device__ __forceinline__ f32x4 xform4_tab(f32x4 v, const float* scale, const f
 // sits in the shadow of MFMAs already issued.  The GroupNorm scale/shift rows the tile needs are
 // staged in LDS once per workgroup (they used to be 8 dependent global loads per thread per step).
 // ---------------------------------------------------------------------------------------
-constexpr int SS_HALF = 512;  // floats of scale (and of shift) kept in LDS per workgroup
 
 // WS = wave-specialised variant: waves [0, WM*WN) only read fragments + issue MFMAs (consumers), waves
 // [WM*WN, 2*WM*WN) only stage tiles (producers: global loads, GroupNorm+SiLU, LDS writes).  Measured on MI355X
@@ -619,8 +575,32 @@ static bool xf_wgrad_ok(const vae_conv_geom& g, int npix, int nsplit, int N) {
   return (N % 4 == 0) && ((int64_t)std::min(nb, g.B) * bn <= SS_HALF);
 }
 extern "C" int vae_xf_fusable_rows(const vae_conv_geom* g, int32_t M, int32_t K) { return g && xf_rows_ok(*g, M, K) ? 1 : 0; }
-extern "C" int vae_xf_fusable_wgrad(const vae_conv_geom* g, int32_t npix, int32_t nsplit, int32_t N) {
-  return g && xf_wgrad_ok(*g, npix, nsplit, N) ? 1 : 0;
+static bool wgrad_vec(const vae_wgrad_args& a) {
+  bool vec = aligned16(a.dY) && aligned16(a.X) && (a.g.Cs % 4 == 0) && (a.ldy % 4 == 0) && (a.M % 4 == 0) &&
+             (a.N % 4 == 0) && (a.sYb % 4 == 0) && (a.sXb % 4 == 0);
+  if (a.xf != VAE_XF_NONE) vec = vec && aligned16(a.scale) && aligned16(a.shift);
+  return vec;
+}
+static bool wgrad_use_tile(const vae_wgrad_args& a) { return wgrad3_tile_eligible(a, wgrad_vec(a)) && !getenv("VAEHIP_FLAT_CONV"); }
+
+// split-K plan: which nsplit to use for these arguments (a->nsplit is ignored) and whether a->xf can be fused.
+// The caller allocates partial[nsplit][M*taps*N] (+ bias_partial[nsplit][M]) accordingly.
+extern "C" int vae_wgrad_plan(const vae_wgrad_args* ap, int32_t* nsplit, int32_t* xf_fusable) {
+  VAE_CHECK(ap && nsplit && xf_fusable, "wgrad_plan: null argument");
+  const vae_wgrad_args& a = *ap;
+  if (wgrad_use_tile(a)) {
+    const int64_t units = wgrad3_tile_units(a.g);
+    const int64_t wgs = (int64_t)((a.M + 127) / 128) * (a.N / 32);
+    int64_t ns = std::max<int64_t>(1, std::min<int64_t>(1024 / std::max<int64_t>(wgs, 1), units / 8));
+    *nsplit = (int32_t)ns;
+    *xf_fusable = 1;
+    return VAE_OK;
+  }
+  const int64_t tiles = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.g.taps;
+  const int64_t ns = std::max<int64_t>(1, std::min<int64_t>(1024 / std::max<int64_t>(tiles, 1), a.npix / 256));
+  *nsplit = (int32_t)ns;
+  *xf_fusable = xf_wgrad_ok(a.g, a.npix, (int)ns, a.N) ? 1 : 0;
+  return VAE_OK;
 }
 
 extern "C" int vae_igemm_rows(const vae_igemm_args* ap, void* stream) {
@@ -644,6 +624,11 @@ extern "C" int vae_igemm_rows(const vae_igemm_args* ap, void* stream) {
   else vec = vec && (a.sn % 4 == 0);
   if (a.xf != VAE_XF_NONE) vec = vec && aligned16(a.scale) && aligned16(a.shift);
   hipStream_t st = (hipStream_t)stream;
+  if (conv3_tile_eligible(a, vec, bkm) && !getenv("VAEHIP_FLAT_CONV")) {  // 3x3 stride-1: LDS halo tile shared by the 9 taps
+    if (int rc2 = launch_conv3_tile(a, bkm, st)) return rc2;
+    VAE_LAUNCH_CHECK("conv3_tile");
+    return VAE_OK;
+  }
   int rc = (a.N <= 32) ? launch_rows<128, 32, 4, 1, false>(a, bkm, vec, st) : launch_rows<128, 128, 4, 2, false>(a, bkm, vec, st);
   if (rc) return rc;
   VAE_LAUNCH_CHECK("igemm_rows");
@@ -663,12 +648,16 @@ extern "C" int vae_wgrad(const vae_wgrad_args* ap, void* stream) {
   VAE_CHECK(a.nsplit == 1 ? a.out != nullptr : a.partial != nullptr, "wgrad: missing output buffer");
   VAE_CHECK(a.xf == VAE_XF_NONE || (a.scale && a.shift), "wgrad: xf needs scale/shift");
   VAE_CHECK(a.bias_partial == nullptr || a.batch == 1, "wgrad: bias_partial is for batch == 1 only");
-  VAE_CHECK(a.xf == VAE_XF_NONE || xf_wgrad_ok(a.g, a.npix, a.nsplit, a.N),
-            "wgrad: fused GroupNorm needs the split's scale/shift rows to fit LDS (see vae_xf_fusable_wgrad)");
-  bool vec = aligned16(a.dY) && aligned16(a.X) && (a.g.Cs % 4 == 0) && (a.ldy % 4 == 0) && (a.M % 4 == 0) &&
-             (a.N % 4 == 0) && (a.sYb % 4 == 0) && (a.sXb % 4 == 0);
-  if (a.xf != VAE_XF_NONE) vec = vec && aligned16(a.scale) && aligned16(a.shift);
+  const bool vec = wgrad_vec(a);
   hipStream_t st = (hipStream_t)stream;
+  if (wgrad_use_tile(a)) {  // 3x3 stride-1: the nine taps share one staged dY tile + X halo
+    VAE_CHECK(a.nsplit <= 65535, "wgrad: nsplit too large");
+    if (int rc2 = launch_wgrad3_tile(a, st)) return rc2;
+    VAE_LAUNCH_CHECK("wgrad3_tile");
+    return VAE_OK;
+  }
+  VAE_CHECK(a.xf == VAE_XF_NONE || xf_wgrad_ok(a.g, a.npix, a.nsplit, a.N),
+            "wgrad: fused GroupNorm needs the split's scale/shift rows to fit LDS (see vae_wgrad_plan)");
   int rc;
   if (a.M <= 32) rc = launch_wgrad<32, 128, 1, 4, false>(a, vec, st);
   else if (a.N <= 32) rc = launch_wgrad<128, 32, 4, 1, false>(a, vec, st);

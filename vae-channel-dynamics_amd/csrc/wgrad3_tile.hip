@@ -1,0 +1,219 @@
+// Weight gradient of a 3x3 stride-1 convolution (plain or over a virtual nearest-2x upsample) with the nine
+// taps sharing one staged tile.
+//
+//   dW[co][tap][ci] = sum_{b,y,x} dY[b][y][x][co] * XF(X)[b][y+kh-1][x+kw-1][ci]
+//
+// Workgroup (12 waves) = 128 output channels (co) x 32 input channels (ci) x ALL 9 taps, over a range of
+// "units" (one unit = 32 consecutive output pixels of one image row).  Per unit it stages dY[32 px][128 co]
+// and the 3x34-pixel halo of X (GroupNorm+SiLU applied while staging): 29 KB per 576 MFMAs, against
+// 32 KB per 256 MFMAs for the flat kernel (igemm.hip wgrad_kernel), and the activation is transformed 3x
+// instead of 9x per co-tile.  Wave w owns co rows (w&3)*32.. and the three taps of filter row kh = w>>2: its dY
+// fragment is read once per 8-pixel group and reused for its 3 taps (3 accumulators = 48 VGPRs).  Both LDS tiles are pixel-major, so a
+// fragment read is one conflict-free ds_read_b32 per k.  LDS is double buffered, one barrier per unit.
+// Split-K over unit ranges; partial slabs are summed in fixed order by vae_reduce_splits (deterministic).
+#include "common.h"
+
+namespace {
+
+constexpr int UPX = 32;                 // pixels per unit
+constexpr int BMT = 128, BNT = 32;      // co tile, ci tile
+constexpr int LDA = BMT + 4;            // dY stage row stride (floats)
+constexpr int HWD = UPX + 2;            // halo width (34)
+constexpr int HPX = 3 * HWD;            // halo pixels (102)
+constexpr int LDH = BNT + 4;            // halo stage row stride
+constexpr int SA = UPX * LDA;           // 4224 floats
+constexpr int SH = HPX * LDH;           // 3672 floats
+constexpr int STAGE = SA + SH;
+constexpr int NT = 768;                                    // 12 waves: 4 co sub-tiles x 3 filter rows
+constexpr int AQ = UPX * (BMT / 4);                        // dY float4 slots (1024)
+constexpr int AI = (AQ + NT - 1) / NT;                     // 2
+constexpr int HQ = HPX * (BNT / 4);                        // halo float4 slots (816)
+constexpr int HI = (HQ + NT - 1) / NT;                     // 2
+
+template <bool UP, int XF>
+__global__ __launch_bounds__(NT) void wgrad3_tile_kernel(vae_wgrad_args p, int xblocks, int64_t nunits) {
+  constexpr int SS = (XF != VAE_XF_NONE) ? 2 * SS_HALF : 0;
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE + SS];
+  float* sS = smem + 2 * STAGE;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int mt = wave & 3, tg = wave >> 2;  // co sub-tile, filter row kh
+  const vae_conv_geom g = p.g;
+  const int tilesN = p.N / BNT;
+  const int tm = blockIdx.x / tilesN, tn = blockIdx.x % tilesN;
+  const int m0 = tm * BMT, n0 = tn * BNT;
+  const int split = blockIdx.y;
+  const int64_t per = (nunits + p.nsplit - 1) / p.nsplit;
+  const int64_t ubeg = split * per, uend = min(nunits, ubeg + per);
+  const int nu = (int)max((int64_t)0, uend - ubeg);
+  const int Hb = UP ? 2 * g.Hs : g.Hs, Wb = UP ? 2 * g.Ws : g.Ws;
+  const bool do_bias = (p.bias_partial != nullptr) && tn == 0;
+  const int rows_per_img = g.Ho * xblocks;  // units per image
+
+  const int b_lo = nu > 0 ? (int)(ubeg / rows_per_img) : 0;
+  if (XF != VAE_XF_NONE && nu > 0) {
+    const int nb = (int)((uend - 1) / rows_per_img) - b_lo + 1;
+    const int nent = min(nb * BNT, SS_HALF);
+    for (int i = tid; i < nent; i += NT) {
+      const int j = i / BNT, c = i - j * BNT;
+      sS[i] = p.scale[(int64_t)(b_lo + j) * g.Cs + n0 + c];
+      sS[SS_HALF + i] = p.shift[(int64_t)(b_lo + j) * g.Cs + n0 + c];
+    }
+  }
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // staging registers
+  f32x4 ra[AI], rh[HI];
+  int hb = 0, hmask = 0;
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+  const int a4 = tid & 31;  // dY: 32 float4 per pixel row; slot q = tid + NT*i keeps the same column quad (NT % 32 == 0)
+
+  auto load_regs = [&](int64_t u) {
+    const int b = (int)(u / rows_per_img);
+    const int rem = (int)(u - (int64_t)b * rows_per_img);
+    const int y = rem / xblocks, xb = rem - y * xblocks;
+    const int64_t pix0 = ((int64_t)b * g.Ho + y) * g.Wo + xb * UPX;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int q = tid + NT * i;
+      const int k = q >> 5;
+      const int c = m0 + a4 * 4;
+      ra[i] = load4g<true>(p.dY + (pix0 + k) * p.ldy + c, q < AQ, p.dY, c, p.M);
+    }
+    hb = b;
+    hmask = 0;
+#pragma unroll
+    for (int i = 0; i < HI; ++i) {
+      const int q = tid + NT * i;
+      const int pp = q >> 3, k4 = q & 7;
+      const int ir = pp / HWD, jc = pp - ir * HWD;
+      const int hy = y - 1 + ir, hx = xb * UPX - 1 + jc;
+      const bool ok = (q < HQ) && ((unsigned)hy < (unsigned)Hb) && ((unsigned)hx < (unsigned)Wb);
+      const int sy = UP ? (hy >> 1) : hy, sx = UP ? (hx >> 1) : hx;
+      const int c = n0 + k4 * 4;
+      rh[i] = load4g<true>(p.X + (((int64_t)b * g.Hs + sy) * g.Ws + sx) * g.Cs + c, ok, p.X, c, p.N);
+      hmask |= (ok ? 1 : 0) << i;
+    }
+  };
+  auto store_lds = [&](float* sA, float* sH) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int q = tid + NT * i;
+      if (q < AQ) {
+        *reinterpret_cast<f32x4*>(&sA[(q >> 5) * LDA + a4 * 4]) = ra[i];
+        if (do_bias) bsum += ra[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < HI; ++i) {
+      const int q = tid + NT * i;
+      if (q < HQ) {
+        f32x4 v = rh[i];
+        if (XF != VAE_XF_NONE) {
+          const bool ok = (hmask >> i) & 1;
+          const int o = ok ? (hb - b_lo) * BNT + (q & 7) * 4 : 0;
+          v = xform4_tab<XF>(v, sS + o, sS + SS_HALF + o, ok);
+        }
+        *reinterpret_cast<f32x4*>(&sH[(q >> 3) * LDH + (q & 7) * 4]) = v;
+      }
+    }
+  };
+  auto compute = [&](const float* sA, const float* sH, int kk) {
+    float a[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] = sA[(kk * 8 + lh * 4 + j) * LDA + mt * 32 + lr];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {  // tap (kh = tg, kw = t)
+      float bq[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bq[j] = sH[(tg * HWD + kk * 8 + lh * 4 + j + t) * LDH + lr];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bq[j], acc[t], 0, 0, 0);
+    }
+  };
+
+  if (nu > 0) {
+    load_regs(ubeg);
+    __syncthreads();  // scale/shift table visible
+    store_lds(smem, smem + SA);
+    if (nu > 1) load_regs(ubeg + 1);
+    __syncthreads();
+    for (int s = 0; s < nu; ++s) {
+      const float* cA = smem + (s & 1) * STAGE;
+      compute(cA, cA + SA, 0);
+      compute(cA, cA + SA, 1);
+      if (s + 1 < nu) {  // staged in the shadow of the MFMAs already issued
+        float* nA = smem + ((s + 1) & 1) * STAGE;
+        store_lds(nA, nA + SA);
+        if (s + 2 < nu) load_regs(ubeg + s + 2);
+      }
+      compute(cA, cA + SA, 2);
+      compute(cA, cA + SA, 3);
+      __syncthreads();
+    }
+  }
+
+  const int64_t ld = (int64_t)9 * p.N;
+  float* __restrict__ O = (p.nsplit == 1 ? p.out : p.partial + (int64_t)split * p.M * ld);
+  const int col = n0 + lr;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int tap = tg * 3 + t;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (row < p.M) O[(int64_t)row * ld + (int64_t)tap * p.N + col] = p.alpha * acc[t][r];
+    }
+  }
+  if (do_bias) {  // workgroup-uniform
+    f32x4* red = reinterpret_cast<f32x4*>(smem);  // [NT/32][32]
+    red[tid] = bsum;                              // tid = rowgroup*32 + a4
+    __syncthreads();
+    if (tid < BMT / 4) {
+      f32x4 t4 = {0.f, 0.f, 0.f, 0.f};
+      for (int r = 0; r < NT / (BMT / 4); ++r) t4 += red[r * (BMT / 4) + tid];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = m0 + tid * 4 + e;
+        if (m < p.M) p.bias_partial[(int64_t)split * p.M + m] = t4[e];
+      }
+    }
+  }
+}
+
+}  // namespace
+
+bool wgrad3_tile_eligible(const vae_wgrad_args& a, bool vec) {
+  const vae_conv_geom& g = a.g;
+  if (!vec || a.batch != 1 || g.taps != 9 || g.stride != 1 || g.pad_t != 1 || g.pad_l != 1) return false;
+  if (a.M <= 32 || a.N % BNT != 0 || g.Wo % UPX != 0) return false;
+  if (g.mode == VAE_MODE_FWD && !(g.Ho == g.Hs && g.Wo == g.Ws)) return false;
+  if (g.mode == VAE_MODE_UP2X && !(g.Ho == 2 * g.Hs && g.Wo == 2 * g.Ws)) return false;
+  if (g.mode == VAE_MODE_DGRAD) return false;
+  if (a.xf != VAE_XF_NONE && (int64_t)g.B * BNT > SS_HALF) return false;
+  return true;
+}
+
+int64_t wgrad3_tile_units(const vae_conv_geom& g) { return (int64_t)g.B * g.Ho * (g.Wo / UPX); }
+
+int launch_wgrad3_tile(const vae_wgrad_args& a, hipStream_t st) {
+  const vae_conv_geom& g = a.g;
+  const int xblocks = g.Wo / UPX;
+  const int64_t nunits = wgrad3_tile_units(g);
+  dim3 grid((unsigned)(((a.M + BMT - 1) / BMT) * (a.N / BNT)), (unsigned)a.nsplit, 1);
+  const bool up = g.mode == VAE_MODE_UP2X;
+#define WG3(UPV, XFV) hipLaunchKernelGGL((wgrad3_tile_kernel<UPV, XFV>), grid, dim3(NT), 0, st, a, xblocks, nunits)
+  switch (a.xf) {
+    case VAE_XF_NONE: if (up) WG3(true, VAE_XF_NONE); else WG3(false, VAE_XF_NONE); break;
+    case VAE_XF_AFFINE: if (up) WG3(true, VAE_XF_AFFINE); else WG3(false, VAE_XF_AFFINE); break;
+    default: if (up) WG3(true, VAE_XF_AFFINE_SILU); else WG3(false, VAE_XF_AFFINE_SILU); break;
+  }
+#undef WG3
+  return 0;
+}

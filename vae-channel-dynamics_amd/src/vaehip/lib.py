@@ -43,7 +43,7 @@ SIGNATURES = {
     "vae_igemm_rows": [C.POINTER(IgemmArgs), vp],
     "vae_wgrad": [C.POINTER(WgradArgs), vp],
     "vae_xf_fusable_rows": [C.POINTER(ConvGeom), i32, i32],
-    "vae_xf_fusable_wgrad": [C.POINTER(ConvGeom), i32, i32, i32],
+    "vae_wgrad_plan": [C.POINTER(WgradArgs), C.POINTER(i32), C.POINTER(i32)],
     "vae_reduce_splits": [vp, i32, i64, vp, vp],
     "vae_colsum": [vp, i64, i32, vp, vp, vp],
     "vae_gn_stats_partial": [vp, i32, i32, i32, i32, i32, vp, vp],

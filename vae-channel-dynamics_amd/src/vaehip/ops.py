@@ -45,7 +45,16 @@ def _launch_igemm(a: IgemmArgs):
     bkm = int(a.sn == 1 and a.sk != 1)
     vec = int(a.g.Cs % 4 == 0 and a.K % 4 == 0 and a.st % 4 == 0 and (a.sn % 4 == 0 if not bkm else (a.sk % 4 == 0 and a.N % 4 == 0)))
     bn = 32 if a.N <= 32 else 128
-    key = f"igemm_rows_kernel<128,{bn},4,{1 if bn == 32 else 2},false,{'true' if bkm else 'false'},{'true' if vec else 'false'},{a.xf}>"
+    g = a.g
+    tile = (vec and a.batch == 1 and g.taps == 9 and g.stride == 1 and g.pad_t == 1 and a.N > 32 and g.Wo % 32 == 0
+            and g.Ho % 4 == 0 and a.alpha == 1.0 and (a.xf == 0 or (a.K <= 512 and not bkm))
+            and ((g.mode == MODE_FWD and not bkm and g.Ho == g.Hs) or (g.mode == MODE_UP2X and not bkm)
+                 or (g.mode == MODE_DGRAD and bkm and a.xf == 0 and g.Ho == g.Hs)))
+    if tile:
+        key = (f"conv3_tile_kernel<{'true' if bkm else 'false'},{'true' if g.mode == MODE_DGRAD else 'false'},"
+               f"{'true' if g.mode == MODE_UP2X else 'false'},{a.xf}>")
+    else:
+        key = f"igemm_rows_kernel<128,{bn},4,{1 if bn == 32 else 2},false,{'true' if bkm else 'false'},{'true' if vec else 'false'},{a.xf}>"
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     lib.call("vae_igemm_rows", C.byref(a), _stream())
@@ -58,8 +67,13 @@ def _launch_wgrad(a: WgradArgs):
         lib.call("vae_wgrad", C.byref(a), _stream())
         return
     vec = int(a.g.Cs % 4 == 0 and a.ldy % 4 == 0 and a.M % 4 == 0 and a.N % 4 == 0)
-    tile = "32,128,1,4,false" if a.M <= 32 else ("128,32,4,1,false" if a.N <= 32 else "128,128,4,2,false")
-    key = f"wgrad_kernel<{tile},{'true' if vec else 'false'},{a.xf}>"
+    g = a.g
+    if (vec and a.batch == 1 and g.taps == 9 and g.stride == 1 and g.pad_t == 1 and a.M > 32 and a.N % 32 == 0
+            and g.Wo % 32 == 0 and g.mode in (MODE_FWD, MODE_UP2X) and (a.xf == 0 or g.B * 32 <= 512)):
+        key = f"wgrad3_tile_kernel<{'true' if g.mode == MODE_UP2X else 'false'},{a.xf}>"
+    else:
+        tile = "32,128,1,4,false" if a.M <= 32 else ("128,32,4,1,false" if a.N <= 32 else "128,128,4,2,false")
+        key = f"wgrad_kernel<{tile},{'true' if vec else 'false'},{a.xf}>"
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     lib.call("vae_wgrad", C.byref(a), _stream())
@@ -196,10 +210,6 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, kind: str, in_hw: Tuple[int, i
     return out
 
 
-def _nsplit(tiles: int, npix: int) -> int:
-    return max(1, min(1024 // max(tiles, 1), npix // 256))
-
-
 def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, kind: str, wgrad_out: torch.Tensor,
                bgrad_out: Optional[torch.Tensor], *, xf: int = XF_NONE, stats: Optional[Stats] = None):
     """writes dW into `wgrad_out` (a view with the weight's OHWI memory) and db into `bgrad_out`."""
@@ -212,12 +222,23 @@ def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, kind: str, wgrad_out: torch.Te
     g = _fwd_geom(kind, B, H, W, Cs)
     assert dy.shape == (B, g.Ho, g.Wo, Co), (dy.shape, (B, g.Ho, g.Wo, Co))
     npix = B * g.Ho * g.Wo
-    tiles = ((Co + 127) // 128) * ((Ci + 127) // 128) * taps
-    ns = _nsplit(tiles, npix)
-    if xf != XF_NONE and not lib.query("vae_xf_fusable_wgrad", C.byref(g), npix, ns, Ci):
-        x, xf = gn_apply(x, stats, xf), XF_NONE
     a = WgradArgs()
     a.dY, a.X = _p(dy), _p(x)
+    a.g = g
+    a.M, a.N, a.ldy, a.npix, a.nsplit = Co, Ci, Co, npix, 1
+    a.batch, a.sYb, a.sXb, a.sOb = 1, 0, 0, 0
+    a.xf, a.alpha = xf, 1.0
+    if xf != XF_NONE:
+        assert stats is not None
+        a.scale, a.shift = _p(stats.scale), _p(stats.shift)
+    ns, fus = C.c_int32(0), C.c_int32(0)
+    lib.call("vae_wgrad_plan", C.byref(a), C.byref(ns), C.byref(fus))
+    if xf != XF_NONE and not fus.value:  # tiny spatial size: several batch items per split
+        x = gn_apply(x, stats, xf)
+        a.X, a.xf, a.scale, a.shift = _p(x), XF_NONE, None, None
+        lib.call("vae_wgrad_plan", C.byref(a), C.byref(ns), C.byref(fus))
+    ns = ns.value
+    a.nsplit = ns
     partial = None
     if ns == 1:
         a.out = _p(gv)
@@ -228,13 +249,6 @@ def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, kind: str, wgrad_out: torch.Te
     if bgrad_out is not None:  # bias gradient = column sums of dY, folded into the wgrad kernel
         bpart = torch.empty((ns, Co), device=x.device, dtype=torch.float32)
         a.bias_partial = _p(bpart)
-    if xf != XF_NONE:
-        assert stats is not None
-        a.scale, a.shift = _p(stats.scale), _p(stats.shift)
-    a.g = g
-    a.M, a.N, a.ldy, a.npix, a.nsplit = Co, Ci, Co, npix, ns
-    a.batch, a.sYb, a.sXb, a.sOb = 1, 0, 0, 0
-    a.xf, a.alpha = xf, 1.0
     _launch_wgrad(a)
     if partial is not None:
         lib.call("vae_reduce_splits", _p(partial), ns, Co * taps * Ci, _p(gv), _stream())
