@@ -156,8 +156,19 @@ def main():
             dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
             ach = dom[1]["flops"] / (dom[1]["ms"] * 1e-3) / 1e12
             allk = sum(v["flops"] for v in summ.values()) / (tot_ms * 1e-3) / 1e12
+            traffic = None  # HBM bytes per launch of this kernel from the committed rocprofv3 --pmc passes (offline)
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
+                    tk = json.load(f)["kernels"]
+                hit = tk.get(dom[0].replace(" ", ""))
+                if hit and B == BATCH_PER_GPU and R == RES:
+                    traffic = round(hit["hbm_bytes_per_launch"])
+            except Exception:
+                traffic = None
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                    "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_hbm_traffic.json)",
+                    "algorithmic_flops_per_launch": round(dom[1]["flops"] / dom[1]["launches"]),
                     "kernel": dom[0], "launches": dom[1]["launches"],
                     "avg_launch_ms": round(dom[1]["ms"] / dom[1]["launches"], 4),
                     "all_contraction_kernels_tflops": round(allk, 2),
