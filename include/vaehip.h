@@ -102,12 +102,12 @@ int vae_wgrad(const vae_wgrad_args* a, void* stream);
 /* split-K plan for `a` (a->nsplit ignored): the nsplit to launch with, and whether a->xf can be fused
  * (0 => materialise XF(X) with vae_gn_apply and pass xf = NONE; only tiny spatial sizes).                */
 int vae_wgrad_plan(const vae_wgrad_args* a, int32_t* nsplit, int32_t* xf_fusable);
+/* name of the kernel instantiation the two entry points dispatch to for these arguments (profiling labels
+ * that match the rocprofv3 kernel names); nothing is launched                                             */
+int vae_igemm_kernel_name(const vae_igemm_args* a, char* buf, int32_t n);
+int vae_wgrad_kernel_name(const vae_wgrad_args* a, char* buf, int32_t n);
 /* out[i] = sum_s partial[s][i], fixed order (deterministic)                     */
 int vae_reduce_splits(const float* partial, int32_t nsplit, int64_t n, float* out, void* stream);
-/* colsum: out[c] = sum_rows X[r][c]  (conv / linear bias gradient) two-stage deterministic;
- * ws needs ceil(rows/1024)*C floats.                                             */
-int vae_colsum(const float* X, int64_t rows, int32_t C, float* ws, float* out, void* stream);
-
 /* ---- GroupNorm (32 groups, eps 1e-6) replaces group_norm fwd/bwd (K2,K7) ---- */
 /* stage 1: per (b, chunk, group) partial sum / sumsq.  ws: [B][nchunk][G][2]     */
 int vae_gn_stats_partial(const float* x, int32_t B, int32_t HW, int32_t C, int32_t G,

@@ -180,28 +180,6 @@ __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, c
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) o[i] = a[i] + b[i];
 }
 
-// ---------------- column sums (bias gradients) ----------------
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, int64_t rows, int C,
-                                                             float* __restrict__ ws) {
-  __shared__ float red[4][64];
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int col = blockIdx.y * 64 + cl;
-  const int64_t r0 = (int64_t)blockIdx.x * 1024, r1 = min(rows, r0 + 1024);
-  float s = 0.f;
-  if (col < C)
-    for (int64_t r = r0 + rl; r < r1; r += 4) s += X[r * C + col];
-  red[rl][cl] = s;
-  __syncthreads();
-  if (rl == 0 && col < C) ws[(int64_t)blockIdx.x * C + col] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
-}
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ ws, int nchunk, int C, float* __restrict__ out) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0;
-  for (int r = 0; r < nchunk; ++r) s += (double)ws[(int64_t)r * C + c];
-  out[c] = (float)s;
-}
-
 // ---------------- grad norm + AdamW ----------------
 __global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ ws) {
   __shared__ float red[4];
@@ -386,17 +364,6 @@ extern "C" int vae_add(const float* a, const float* b, int64_t n, float* out, vo
   VAE_CHECK(a && b && out && n > 0, "add: bad args");
   hipLaunchKernelGGL(add_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, n, out);
   VAE_LAUNCH_CHECK("add");
-  return VAE_OK;
-}
-
-extern "C" int vae_colsum(const float* X, int64_t rows, int32_t C, float* ws, float* out, void* stream) {
-  VAE_CHECK(X && ws && out && rows > 0 && C > 0, "colsum: bad args");
-  const int64_t nchunk = (rows + 1023) / 1024;
-  VAE_CHECK(nchunk < (1ll << 31) && (C + 63) / 64 <= 65535, "colsum: too large");
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)nchunk, (unsigned)((C + 63) / 64)), dim3(256), 0, (hipStream_t)stream, X,
-                     rows, C, ws);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, (int)nchunk, C, out);
-  VAE_LAUNCH_CHECK("colsum");
   return VAE_OK;
 }
 

@@ -36,16 +36,11 @@ constexpr int BK = 32;
 // staged in LDS once per workgroup (they used to be 8 dependent global loads per thread per step).
 // ---------------------------------------------------------------------------------------
 
-// WS = wave-specialised variant: waves [0, WM*WN) only read fragments + issue MFMAs (consumers), waves
-// [WM*WN, 2*WM*WN) only stage tiles (producers: global loads, GroupNorm+SiLU, LDS writes).  Measured on MI355X
-// (tools/microbench.py, 512->512 @64^2 and 128->128 @256^2, B=16): 0...-8 % against the unified 8-wave
-// 128x128 workgroup (<128,128,4,2,false>), which is therefore the one dispatched; WS stays selectable for
-// re-measurement on other tile shapes.
-template <int BM, int BN, int WM, int WN, bool WS, bool BKM, bool VEC, int XF>
-__global__ __launch_bounds__((WS ? 128 : 64) * WM * WN) void igemm_rows_kernel(vae_igemm_args p) {
-  constexpr int NL = 64 * WM * WN;      // loader threads (== consumer threads)
-  constexpr int NT = WS ? 2 * NL : NL;  // workgroup size
-  constexpr int RP = NL / 8;            // tile rows covered by one pass of the float4 loaders
+template <int BM, int BN, int WM, int WN, bool BKM, bool VEC, int XF>
+__global__ __launch_bounds__(64 * WM * WN) void igemm_rows_kernel(vae_igemm_args p) {
+  constexpr int NT = 64 * WM * WN;  // 4 waves (skinny tiles) or 8 waves (128x128: 4 waves/SIMD at 2 workgroups/CU)
+  constexpr int NL = NT;
+  constexpr int RP = NT / 8;        // tile rows covered by one pass of the float4 loaders
   constexpr int LDA = BK + 4;
   constexpr int LDB = BKM ? (BN + 4) : (BK + 4);
   constexpr int SA = BM * LDA;
@@ -60,10 +55,8 @@ __global__ __launch_bounds__((WS ? 128 : 64) * WM * WN) void igemm_rows_kernel(v
   float* sS = smem + 2 * STAGE;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const bool prod = !WS || tid >= NL;  // wave-uniform roles
-  const bool cons = !WS || tid < NL;
-  const int lt = WS ? (tid & (NL - 1)) : tid;  // loader-thread index
-  const int wm = (wave % (WM * WN)) / WN, wn = wave % WN;
+  const int lt = tid;
+  const int wm = wave / WN, wn = wave % WN;
   const int tilesN = (p.N + BN - 1) / BN;
   const int tm = blockIdx.x / tilesN, tn = blockIdx.x % tilesN;
   const int m0 = tm * BM, n0 = tn * BN;
@@ -197,53 +190,24 @@ __global__ __launch_bounds__((WS ? 128 : 64) * WM * WN) void igemm_rows_kernel(v
     __builtin_amdgcn_s_setprio(0);
   };
 
-  if (!WS) {
-    load_regs(0);
-    __syncthreads();  // scale/shift table visible
-    store_lds(smem, smem + SA);
-    if (steps > 1) load_regs(1);
-    __syncthreads();
-    for (int s = 0; s < steps; ++s) {
-      const float* cA = smem + (s & 1) * STAGE;
-      const float* cB = cA + SA;
-      compute(cA, cB, 0);
-      compute(cA, cB, 1);
-      if (s + 1 < steps) {
-        float* nA = smem + ((s + 1) & 1) * STAGE;
-        store_lds(nA, nA + SA);
-        if (s + 2 < steps) load_regs(s + 2);
-      }
-      compute(cA, cB, 2);
-      compute(cA, cB, 3);
-      __syncthreads();
+  load_regs(0);
+  __syncthreads();  // scale/shift table visible
+  store_lds(smem, smem + SA);
+  if (steps > 1) load_regs(1);
+  __syncthreads();
+  for (int s = 0; s < steps; ++s) {
+    const float* cA = smem + (s & 1) * STAGE;
+    const float* cB = cA + SA;
+    compute(cA, cB, 0);
+    compute(cA, cB, 1);
+    if (s + 1 < steps) {  // staged in the shadow of the MFMAs already issued
+      float* nA = smem + ((s + 1) & 1) * STAGE;
+      store_lds(nA, nA + SA);
+      if (s + 2 < steps) load_regs(s + 2);
     }
-  } else if (prod) {
-    // producer waves: every wave of the workgroup executes the same number of barriers (2 + steps)
-    load_regs(0);
-    __syncthreads();  // scale/shift table visible
-    store_lds(smem, smem + SA);
-    if (steps > 1) load_regs(1);
+    compute(cA, cB, 2);
+    compute(cA, cB, 3);
     __syncthreads();
-    for (int s = 0; s < steps; ++s) {
-      if (s + 1 < steps) {
-        float* nA = smem + ((s + 1) & 1) * STAGE;
-        store_lds(nA, nA + SA);  // stage (s+1)&1 was last read in step s-1, which every consumer has left
-        if (s + 2 < steps) load_regs(s + 2);
-      }
-      __syncthreads();
-    }
-  } else {
-    __syncthreads();
-    __syncthreads();
-    for (int s = 0; s < steps; ++s) {
-      const float* cA = smem + (s & 1) * STAGE;
-      const float* cB = cA + SA;
-      compute(cA, cB, 0);
-      compute(cA, cB, 1);
-      compute(cA, cB, 2);
-      compute(cA, cB, 3);
-      __syncthreads();
-    }
   }
 
   // ---------------- epilogue ----------------
@@ -262,7 +226,7 @@ __global__ __launch_bounds__((WS ? 128 : 64) * WM * WN) void igemm_rows_kernel(v
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * TM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (cons && colok && row < p.M) {
+        if (colok && row < p.M) {
           float v = p.alpha * acc[mi][ni][r] + bv;
           const int64_t o = (int64_t)row * p.ldc + col;
           if (R) v += R[o];
@@ -277,7 +241,7 @@ __global__ __launch_bounds__((WS ? 128 : 64) * WM * WN) void igemm_rows_kernel(v
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
       float s2 = tsum[ni] + __shfl_xor(tsum[ni], 32, 64);
-      if (cons && lh == 0) red[wm * BN + wn * TN + ni * 32 + lr] = s2;
+      if (lh == 0) red[wm * BN + wn * TN + ni * 32 + lr] = s2;
     }
     __syncthreads();
     if (tid < BN) {
@@ -294,10 +258,10 @@ __global__ __launch_bounds__((WS ? 128 : 64) * WM * WN) void igemm_rows_kernel(v
 // Same double-buffered one-barrier pipeline.  The bias gradient (column sums of dY) is folded in:
 // workgroups with tn == 0 and tap == 0 add up the dY tiles they stage anyway.
 // ---------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, bool WS, bool VEC, int XF>
-__global__ __launch_bounds__((WS ? 128 : 64) * WM * WN) void wgrad_kernel(vae_wgrad_args p) {
-  constexpr int NL = 64 * WM * WN;
-  constexpr int NT = WS ? 2 * NL : NL;
+template <int BM, int BN, int WM, int WN, bool VEC, int XF>
+__global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(vae_wgrad_args p) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int NL = NT;
   constexpr int LDA = BM + 4, LDB = BN + 4;
   constexpr int SA = BK * LDA, SB = BK * LDB;
   constexpr int STAGE = SA + SB;
@@ -310,10 +274,8 @@ __global__ __launch_bounds__((WS ? 128 : 64) * WM * WN) void wgrad_kernel(vae_wg
   float* sS = smem + 2 * STAGE;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const bool prod = !WS || tid >= NL;
-  const bool cons = !WS || tid < NL;
-  const int lt = WS ? (tid & (NL - 1)) : tid;
-  const int wm = (wave % (WM * WN)) / WN, wn = wave % WN;
+  const int lt = tid;
+  const int wm = wave / WN, wn = wave % WN;
   const int tilesN = (p.N + BN - 1) / BN;
   const int tm = blockIdx.x / tilesN, tn = blockIdx.x % tilesN;
   const int m0 = tm * BM, n0 = tn * BN;
@@ -421,52 +383,24 @@ __global__ __launch_bounds__((WS ? 128 : 64) * WM * WN) void wgrad_kernel(vae_wg
   };
 
   if (steps > 0) {
-    if (!WS) {
-      load_regs(0);
-      __syncthreads();  // scale/shift table visible
-      store_lds(smem, smem + SA);
-      if (steps > 1) load_regs(1);
-      __syncthreads();
-      for (int s = 0; s < steps; ++s) {
-        const float* cA = smem + (s & 1) * STAGE;
-        const float* cB = cA + SA;
-        compute(cA, cB, 0);
-        compute(cA, cB, 1);
-        if (s + 1 < steps) {
-          float* nA = smem + ((s + 1) & 1) * STAGE;
-          store_lds(nA, nA + SA);
-          if (s + 2 < steps) load_regs(s + 2);
-        }
-        compute(cA, cB, 2);
-        compute(cA, cB, 3);
-        __syncthreads();
+    load_regs(0);
+    __syncthreads();  // scale/shift table visible
+    store_lds(smem, smem + SA);
+    if (steps > 1) load_regs(1);
+    __syncthreads();
+    for (int s = 0; s < steps; ++s) {
+      const float* cA = smem + (s & 1) * STAGE;
+      const float* cB = cA + SA;
+      compute(cA, cB, 0);
+      compute(cA, cB, 1);
+      if (s + 1 < steps) {
+        float* nA = smem + ((s + 1) & 1) * STAGE;
+        store_lds(nA, nA + SA);
+        if (s + 2 < steps) load_regs(s + 2);
       }
-    } else if (prod) {
-      load_regs(0);
+      compute(cA, cB, 2);
+      compute(cA, cB, 3);
       __syncthreads();
-      store_lds(smem, smem + SA);
-      if (steps > 1) load_regs(1);
-      __syncthreads();
-      for (int s = 0; s < steps; ++s) {
-        if (s + 1 < steps) {
-          float* nA = smem + ((s + 1) & 1) * STAGE;
-          store_lds(nA, nA + SA);
-          if (s + 2 < steps) load_regs(s + 2);
-        }
-        __syncthreads();
-      }
-    } else {
-      __syncthreads();
-      __syncthreads();
-      for (int s = 0; s < steps; ++s) {
-        const float* cA = smem + (s & 1) * STAGE;
-        const float* cB = cA + SA;
-        compute(cA, cB, 0);
-        compute(cA, cB, 1);
-        compute(cA, cB, 2);
-        compute(cA, cB, 3);
-        __syncthreads();
-      }
     }
   }
 
@@ -481,12 +415,12 @@ __global__ __launch_bounds__((WS ? 128 : 64) * WM * WN) void wgrad_kernel(vae_wg
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * TM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (cons && row < p.M) O[(int64_t)row * ld + (int64_t)tap * p.N + col] = p.alpha * acc[mi][ni][r];
+        if (row < p.M) O[(int64_t)row * ld + (int64_t)tap * p.N + col] = p.alpha * acc[mi][ni][r];
       }
   }
   if (do_bias) {  // uniform per workgroup
     f32x4* red = reinterpret_cast<f32x4*>(smem);  // [AKR][AQ]
-    if (prod) red[akq * AQ + a4] = bsum;
+    red[akq * AQ + a4] = bsum;
     __syncthreads();
     if (tid < AQ) {
       f32x4 t = {0.f, 0.f, 0.f, 0.f};
@@ -510,43 +444,43 @@ __global__ void reduce_splits_kernel(const float* __restrict__ partial, int nspl
   }
 }
 
-template <int BM, int BN, int WM, int WN, bool WS, bool BKM, bool VEC>
+template <int BM, int BN, int WM, int WN, bool BKM, bool VEC>
 int launch_rows_xf(const vae_igemm_args& a, dim3 grid, hipStream_t st) {
   if (BKM) {
     if (a.xf != VAE_XF_NONE) { vae_set_error("igemm_rows: xf unsupported with n-contiguous weights"); return VAE_EINVAL; }
-    hipLaunchKernelGGL((igemm_rows_kernel<BM, BN, WM, WN, WS, BKM, VEC, VAE_XF_NONE>), grid, dim3((WS ? 128 : 64) * WM * WN), 0, st, a);
+    hipLaunchKernelGGL((igemm_rows_kernel<BM, BN, WM, WN, BKM, VEC, VAE_XF_NONE>), grid, dim3(64 * WM * WN), 0, st, a);
     return 0;
   }
   switch (a.xf) {
-    case VAE_XF_NONE: hipLaunchKernelGGL((igemm_rows_kernel<BM, BN, WM, WN, WS, false, VEC, VAE_XF_NONE>), grid, dim3((WS ? 128 : 64) * WM * WN), 0, st, a); break;
-    case VAE_XF_AFFINE: hipLaunchKernelGGL((igemm_rows_kernel<BM, BN, WM, WN, WS, false, VEC, VAE_XF_AFFINE>), grid, dim3((WS ? 128 : 64) * WM * WN), 0, st, a); break;
-    case VAE_XF_AFFINE_SILU: hipLaunchKernelGGL((igemm_rows_kernel<BM, BN, WM, WN, WS, false, VEC, VAE_XF_AFFINE_SILU>), grid, dim3((WS ? 128 : 64) * WM * WN), 0, st, a); break;
+    case VAE_XF_NONE: hipLaunchKernelGGL((igemm_rows_kernel<BM, BN, WM, WN, false, VEC, VAE_XF_NONE>), grid, dim3(64 * WM * WN), 0, st, a); break;
+    case VAE_XF_AFFINE: hipLaunchKernelGGL((igemm_rows_kernel<BM, BN, WM, WN, false, VEC, VAE_XF_AFFINE>), grid, dim3(64 * WM * WN), 0, st, a); break;
+    case VAE_XF_AFFINE_SILU: hipLaunchKernelGGL((igemm_rows_kernel<BM, BN, WM, WN, false, VEC, VAE_XF_AFFINE_SILU>), grid, dim3(64 * WM * WN), 0, st, a); break;
     default: vae_set_error("igemm_rows: bad xf %d", a.xf); return VAE_EINVAL;
   }
   return 0;
 }
 
-template <int BM, int BN, int WM, int WN, bool WS>
+template <int BM, int BN, int WM, int WN>
 int launch_rows(const vae_igemm_args& a, bool bkm, bool vec, hipStream_t st) {
   dim3 grid((unsigned)(((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN)), 1, (unsigned)a.batch);
-  if (bkm) return vec ? launch_rows_xf<BM, BN, WM, WN, WS, true, true>(a, grid, st) : launch_rows_xf<BM, BN, WM, WN, WS, true, false>(a, grid, st);
-  return vec ? launch_rows_xf<BM, BN, WM, WN, WS, false, true>(a, grid, st) : launch_rows_xf<BM, BN, WM, WN, WS, false, false>(a, grid, st);
+  if (bkm) return vec ? launch_rows_xf<BM, BN, WM, WN, true, true>(a, grid, st) : launch_rows_xf<BM, BN, WM, WN, true, false>(a, grid, st);
+  return vec ? launch_rows_xf<BM, BN, WM, WN, false, true>(a, grid, st) : launch_rows_xf<BM, BN, WM, WN, false, false>(a, grid, st);
 }
 
-template <int BM, int BN, int WM, int WN, bool WS, bool VEC>
+template <int BM, int BN, int WM, int WN, bool VEC>
 int launch_wgrad_xf(const vae_wgrad_args& a, dim3 grid, hipStream_t st) {
   switch (a.xf) {
-    case VAE_XF_NONE: hipLaunchKernelGGL((wgrad_kernel<BM, BN, WM, WN, WS, VEC, VAE_XF_NONE>), grid, dim3((WS ? 128 : 64) * WM * WN), 0, st, a); break;
-    case VAE_XF_AFFINE: hipLaunchKernelGGL((wgrad_kernel<BM, BN, WM, WN, WS, VEC, VAE_XF_AFFINE>), grid, dim3((WS ? 128 : 64) * WM * WN), 0, st, a); break;
-    case VAE_XF_AFFINE_SILU: hipLaunchKernelGGL((wgrad_kernel<BM, BN, WM, WN, WS, VEC, VAE_XF_AFFINE_SILU>), grid, dim3((WS ? 128 : 64) * WM * WN), 0, st, a); break;
+    case VAE_XF_NONE: hipLaunchKernelGGL((wgrad_kernel<BM, BN, WM, WN, VEC, VAE_XF_NONE>), grid, dim3(64 * WM * WN), 0, st, a); break;
+    case VAE_XF_AFFINE: hipLaunchKernelGGL((wgrad_kernel<BM, BN, WM, WN, VEC, VAE_XF_AFFINE>), grid, dim3(64 * WM * WN), 0, st, a); break;
+    case VAE_XF_AFFINE_SILU: hipLaunchKernelGGL((wgrad_kernel<BM, BN, WM, WN, VEC, VAE_XF_AFFINE_SILU>), grid, dim3(64 * WM * WN), 0, st, a); break;
     default: vae_set_error("wgrad: bad xf %d", a.xf); return VAE_EINVAL;
   }
   return 0;
 }
-template <int BM, int BN, int WM, int WN, bool WS>
+template <int BM, int BN, int WM, int WN>
 int launch_wgrad(const vae_wgrad_args& a, bool vec, hipStream_t st) {
   dim3 grid((unsigned)(((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN)), (unsigned)(a.g.taps * a.nsplit), (unsigned)a.batch);
-  return vec ? launch_wgrad_xf<BM, BN, WM, WN, WS, true>(a, grid, st) : launch_wgrad_xf<BM, BN, WM, WN, WS, false>(a, grid, st);
+  return vec ? launch_wgrad_xf<BM, BN, WM, WN, true>(a, grid, st) : launch_wgrad_xf<BM, BN, WM, WN, false>(a, grid, st);
 }
 
 int check_geom(const char* who, const vae_conv_geom& g) {
@@ -603,6 +537,44 @@ extern "C" int vae_wgrad_plan(const vae_wgrad_args* ap, int32_t* nsplit, int32_t
   return VAE_OK;
 }
 
+static bool rows_bkm(const vae_igemm_args& a) { return (a.sn == 1) && (a.sk != 1); }
+static bool rows_vec(const vae_igemm_args& a, bool bkm) {
+  bool vec = aligned16(a.A) && aligned16(a.W) && (a.g.Cs % 4 == 0) && (a.K % 4 == 0) && (a.st % 4 == 0) &&
+             (a.sAb % 4 == 0) && (a.sWb % 4 == 0);
+  if (bkm) vec = vec && (a.sk % 4 == 0) && (a.N % 4 == 0);
+  else vec = vec && (a.sn % 4 == 0);
+  if (a.xf != VAE_XF_NONE) vec = vec && aligned16(a.scale) && aligned16(a.shift);
+  return vec;
+}
+static bool rows_use_tile(const vae_igemm_args& a, bool vec, bool bkm) {
+  return conv3_tile_eligible(a, vec, bkm) && !getenv("VAEHIP_FLAT_CONV");
+}
+
+// name of the kernel instantiation vae_igemm_rows / vae_wgrad dispatch to for these arguments
+// (profiling labels that match the rocprofv3 kernel names; no launch)
+extern "C" int vae_igemm_kernel_name(const vae_igemm_args* ap, char* buf, int32_t n) {
+  VAE_CHECK(ap && buf && n > 0, "igemm_kernel_name: bad args");
+  const vae_igemm_args& a = *ap;
+  const bool bkm = rows_bkm(a), vec = rows_vec(a, bkm);
+  const char* tf[2] = {"false", "true"};
+  if (rows_use_tile(a, vec, bkm))
+    snprintf(buf, n, "conv3_tile_kernel<%s,%s,%s,%d>", tf[bkm], tf[a.g.mode == VAE_MODE_DGRAD], tf[a.g.mode == VAE_MODE_UP2X], a.xf);
+  else if (a.N <= 32)
+    snprintf(buf, n, "igemm_rows_kernel<128,32,4,1,%s,%s,%d>", tf[bkm], tf[vec], a.xf);
+  else
+    snprintf(buf, n, "igemm_rows_kernel<128,128,4,2,%s,%s,%d>", tf[bkm], tf[vec], a.xf);
+  return VAE_OK;
+}
+extern "C" int vae_wgrad_kernel_name(const vae_wgrad_args* ap, char* buf, int32_t n) {
+  VAE_CHECK(ap && buf && n > 0, "wgrad_kernel_name: bad args");
+  const vae_wgrad_args& a = *ap;
+  const bool vec = wgrad_vec(a);
+  const char* tf[2] = {"false", "true"};
+  if (wgrad_use_tile(a)) snprintf(buf, n, "wgrad3_tile_kernel<%s,%d>", tf[a.g.mode == VAE_MODE_UP2X], a.xf);
+  else snprintf(buf, n, "wgrad_kernel<%s,%s,%d>", a.M <= 32 ? "32,128,1,4" : (a.N <= 32 ? "128,32,4,1" : "128,128,4,2"), tf[vec], a.xf);
+  return VAE_OK;
+}
+
 extern "C" int vae_igemm_rows(const vae_igemm_args* ap, void* stream) {
   VAE_CHECK(ap != nullptr, "igemm_rows: null args");
   const vae_igemm_args& a = *ap;
@@ -617,19 +589,15 @@ extern "C" int vae_igemm_rows(const vae_igemm_args* ap, void* stream) {
   VAE_CHECK(a.xf == VAE_XF_NONE || (a.scale && a.shift), "igemm_rows: xf needs scale/shift");
   VAE_CHECK(a.xf == VAE_XF_NONE || xf_rows_ok(a.g, a.M, a.K),
             "igemm_rows: fused GroupNorm needs the tile's scale/shift rows to fit LDS (see vae_xf_fusable_rows)");
-  const bool bkm = (a.sn == 1) && (a.sk != 1);
-  bool vec = aligned16(a.A) && aligned16(a.W) && (a.g.Cs % 4 == 0) && (a.K % 4 == 0) && (a.st % 4 == 0) &&
-             (a.sAb % 4 == 0) && (a.sWb % 4 == 0);
-  if (bkm) vec = vec && (a.sk % 4 == 0) && (a.N % 4 == 0);
-  else vec = vec && (a.sn % 4 == 0);
-  if (a.xf != VAE_XF_NONE) vec = vec && aligned16(a.scale) && aligned16(a.shift);
+  const bool bkm = rows_bkm(a);
+  const bool vec = rows_vec(a, bkm);
   hipStream_t st = (hipStream_t)stream;
-  if (conv3_tile_eligible(a, vec, bkm) && !getenv("VAEHIP_FLAT_CONV")) {  // 3x3 stride-1: LDS halo tile shared by the 9 taps
+  if (rows_use_tile(a, vec, bkm)) {  // 3x3 stride-1: LDS halo tile shared by the 9 taps
     if (int rc2 = launch_conv3_tile(a, bkm, st)) return rc2;
     VAE_LAUNCH_CHECK("conv3_tile");
     return VAE_OK;
   }
-  int rc = (a.N <= 32) ? launch_rows<128, 32, 4, 1, false>(a, bkm, vec, st) : launch_rows<128, 128, 4, 2, false>(a, bkm, vec, st);
+  int rc = (a.N <= 32) ? launch_rows<128, 32, 4, 1>(a, bkm, vec, st) : launch_rows<128, 128, 4, 2>(a, bkm, vec, st);
   if (rc) return rc;
   VAE_LAUNCH_CHECK("igemm_rows");
   return VAE_OK;
@@ -659,9 +627,9 @@ extern "C" int vae_wgrad(const vae_wgrad_args* ap, void* stream) {
   VAE_CHECK(a.xf == VAE_XF_NONE || xf_wgrad_ok(a.g, a.npix, a.nsplit, a.N),
             "wgrad: fused GroupNorm needs the split's scale/shift rows to fit LDS (see vae_wgrad_plan)");
   int rc;
-  if (a.M <= 32) rc = launch_wgrad<32, 128, 1, 4, false>(a, vec, st);
-  else if (a.N <= 32) rc = launch_wgrad<128, 32, 4, 1, false>(a, vec, st);
-  else rc = launch_wgrad<128, 128, 4, 2, false>(a, vec, st);
+  if (a.M <= 32) rc = launch_wgrad<32, 128, 1, 4>(a, vec, st);
+  else if (a.N <= 32) rc = launch_wgrad<128, 32, 4, 1>(a, vec, st);
+  else rc = launch_wgrad<128, 128, 4, 2>(a, vec, st);
   if (rc) return rc;
   VAE_LAUNCH_CHECK("wgrad");
   return VAE_OK;

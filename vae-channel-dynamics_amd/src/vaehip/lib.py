@@ -44,8 +44,9 @@ SIGNATURES = {
     "vae_wgrad": [C.POINTER(WgradArgs), vp],
     "vae_xf_fusable_rows": [C.POINTER(ConvGeom), i32, i32],
     "vae_wgrad_plan": [C.POINTER(WgradArgs), C.POINTER(i32), C.POINTER(i32)],
+    "vae_igemm_kernel_name": [C.POINTER(IgemmArgs), C.c_char_p, i32],
+    "vae_wgrad_kernel_name": [C.POINTER(WgradArgs), C.c_char_p, i32],
     "vae_reduce_splits": [vp, i32, i64, vp, vp],
-    "vae_colsum": [vp, i64, i32, vp, vp, vp],
     "vae_gn_stats_partial": [vp, i32, i32, i32, i32, i32, vp, vp],
     "vae_gn_stats_final": [vp, i32, i32, i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp],
     "vae_gn_apply": [vp, vp, vp, i32, i32, i32, i32, vp, vp],

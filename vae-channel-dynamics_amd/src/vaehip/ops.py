@@ -38,47 +38,32 @@ class LaunchProfiler:
 PROFILER: Optional[LaunchProfiler] = None
 
 
+def _kernel_name(fn: str, a) -> str:
+    buf = C.create_string_buffer(128)
+    lib.call(fn, C.byref(a), buf, 128)
+    return buf.value.decode()
+
+
 def _launch_igemm(a: IgemmArgs):
     if PROFILER is None:
         lib.call("vae_igemm_rows", C.byref(a), _stream())
         return
-    bkm = int(a.sn == 1 and a.sk != 1)
-    vec = int(a.g.Cs % 4 == 0 and a.K % 4 == 0 and a.st % 4 == 0 and (a.sn % 4 == 0 if not bkm else (a.sk % 4 == 0 and a.N % 4 == 0)))
-    bn = 32 if a.N <= 32 else 128
-    g = a.g
-    tile = (vec and a.batch == 1 and g.taps == 9 and g.stride == 1 and g.pad_t == 1 and a.N > 32 and g.Wo % 32 == 0
-            and g.Ho % 4 == 0 and a.alpha == 1.0 and (a.xf == 0 or (a.K <= 512 and not bkm))
-            and ((g.mode == MODE_FWD and not bkm and g.Ho == g.Hs) or (g.mode == MODE_UP2X and not bkm)
-                 or (g.mode == MODE_DGRAD and bkm and a.xf == 0 and g.Ho == g.Hs)))
-    if tile:
-        key = (f"conv3_tile_kernel<{'true' if bkm else 'false'},{'true' if g.mode == MODE_DGRAD else 'false'},"
-               f"{'true' if g.mode == MODE_UP2X else 'false'},{a.xf}>")
-    else:
-        key = f"igemm_rows_kernel<128,{bn},4,{1 if bn == 32 else 2},false,{'true' if bkm else 'false'},{'true' if vec else 'false'},{a.xf}>"
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     lib.call("vae_igemm_rows", C.byref(a), _stream())
     e1.record()
-    PROFILER.records.append((key, 2.0 * a.M * a.N * a.K * a.g.taps * a.batch, e0, e1))
+    PROFILER.records.append((_kernel_name("vae_igemm_kernel_name", a), 2.0 * a.M * a.N * a.K * a.g.taps * a.batch, e0, e1))
 
 
 def _launch_wgrad(a: WgradArgs):
     if PROFILER is None:
         lib.call("vae_wgrad", C.byref(a), _stream())
         return
-    vec = int(a.g.Cs % 4 == 0 and a.ldy % 4 == 0 and a.M % 4 == 0 and a.N % 4 == 0)
-    g = a.g
-    if (vec and a.batch == 1 and g.taps == 9 and g.stride == 1 and g.pad_t == 1 and a.M > 32 and a.N % 32 == 0
-            and g.Wo % 32 == 0 and g.mode in (MODE_FWD, MODE_UP2X) and (a.xf == 0 or g.B * 32 <= 512)):
-        key = f"wgrad3_tile_kernel<{'true' if g.mode == MODE_UP2X else 'false'},{a.xf}>"
-    else:
-        tile = "32,128,1,4,false" if a.M <= 32 else ("128,32,4,1,false" if a.N <= 32 else "128,128,4,2,false")
-        key = f"wgrad_kernel<{tile},{'true' if vec else 'false'},{a.xf}>"
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     lib.call("vae_wgrad", C.byref(a), _stream())
     e1.record()
-    PROFILER.records.append((key, 2.0 * a.M * a.N * a.npix * a.g.taps * a.batch, e0, e1))
+    PROFILER.records.append((_kernel_name("vae_wgrad_kernel_name", a), 2.0 * a.M * a.N * a.npix * a.g.taps * a.batch, e0, e1))
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -254,12 +239,6 @@ def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, kind: str, wgrad_out: torch.Te
         lib.call("vae_reduce_splits", _p(partial), ns, Co * taps * Ci, _p(gv), _stream())
     if bpart is not None:
         lib.call("vae_reduce_splits", _p(bpart), ns, Co, _p(bgrad_out), _stream())
-
-
-def colsum(x2d: torch.Tensor, out: torch.Tensor):
-    rows, Cc = x2d.shape
-    ws = torch.empty(((rows + 1023) // 1024, Cc), device=x2d.device, dtype=torch.float32)
-    lib.call("vae_colsum", _p(x2d), rows, Cc, _p(ws), _p(out), _stream())
 
 
 # ------------------------------------------------------------------ GroupNorm
