@@ -24,6 +24,7 @@ import torch.distributed as dist  # noqa: E402
 RES = 256
 BATCH_PER_GPU = 16
 MFMA_F32_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 (the 5 PF headline includes 2:1 sparsity)
 TRACKING_CFG = {
     "enabled": True, "track_interval": 20,
     "target_layers": [
@@ -79,6 +80,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="per-GPU batch (default = BASELINE config)")
     ap.add_argument("--res", type=int, default=RES)
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32 = BASELINE configs[1] (the metric); bf16 = configs[2]-style compute (bf16 MFMA, fp32 accumulate/storage)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tracking", action="store_true", help="A/B switch for the tracker-overhead measurement")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP-event timing")
@@ -104,7 +107,8 @@ def main():
     torch.manual_seed(42)
     w = SDXLVAEWrapper("synthetic:42", device=dev)
     trainer = HipTrainer(w, lr=1e-5, max_grad_norm=1.0, kl_weight=1e-6, lr_warmup_steps=100,
-                         max_train_steps=10000, scheduler_steps_per_update=world)
+                         max_train_steps=10000, scheduler_steps_per_update=world,
+                         mixed_precision="bf16" if args.dtype == "bf16" else "no")
     monitor = None if args.no_tracking else ActivityMonitor(w, TRACKING_CFG)
     classifier = None if args.no_tracking else RegionClassifier(w.vae, CLASSIFY_CFG)
 
@@ -161,12 +165,13 @@ def main():
                 with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
                     tk = json.load(f)["kernels"]
                 hit = tk.get(dom[0].replace(" ", ""))
-                if hit and B == BATCH_PER_GPU and R == RES:
+                if hit and B == BATCH_PER_GPU and R == RES and args.dtype == "f32":
                     traffic = round(hit["hbm_bytes_per_launch"])
             except Exception:
                 traffic = None
-            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
+            peak = MFMA_F32_PEAK_TFLOPS if "bf16" not in dom[0] else MFMA_BF16_PEAK_TFLOPS
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": traffic,
                     "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_hbm_traffic.json)",
                     "algorithmic_flops_per_launch": round(dom[1]["flops"] / dom[1]["launches"]),
                     "kernel": dom[0], "launches": dom[1]["launches"],
@@ -181,8 +186,9 @@ def main():
             "value": round(world * B * args.steps / dt, 3), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: SDXL-VAE {R}x{R} synthetic RGB, batch {B}/GPU, fp32, "
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[{1 if args.dtype == 'f32' else 2}]: SDXL-VAE {R}x{R} synthetic RGB, batch {B}/GPU, "
+                                   f"{'fp32' if args.dtype == 'f32' else 'bf16 MFMA compute (fp32 accumulate, fp32 tensors/master weights)'}, "
                                    f"tracking {'off' if args.no_tracking else 'on (3 layers) + classifier'}, no nudge; "
                                    f"random-init weights (synthetic:42)",
                        "global_batch": world * B, "resolution": R, "parallelism": f"dp{world}"},

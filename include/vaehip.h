@@ -39,6 +39,12 @@ int vae_abi_version(void);
 #define VAE_XF_AFFINE 1      /* x*scale[b][c]+shift[b][c]            (GroupNorm, no activation) */
 #define VAE_XF_AFFINE_SILU 2 /* silu(x*scale[b][c]+shift[b][c])      (GroupNorm + SiLU)         */
 
+/* arithmetic of the contraction.  Tensors in HBM are fp32 in both modes (fp32 master weights / statistics);
+ * BF16 rounds the operands to bf16 while staging them in LDS and multiplies on v_mfma_f32_32x32x16_bf16 with
+ * fp32 accumulation (`training.mixed_precision: bf16`).  Shapes without a bf16 kernel run the fp32 one.   */
+#define VAE_PREC_F32 0
+#define VAE_PREC_BF16 1
+
 /* how a row (b,y,x) of the GEMM maps onto the source tensor */
 #define VAE_MODE_FWD 0   /* sy = y*stride + kh - pad_t                          */
 #define VAE_MODE_UP2X 1  /* source is virtually nearest-upsampled 2x, 3x3 pad 1 */
@@ -74,6 +80,7 @@ typedef struct vae_igemm_args {
   int64_t sAb, sWb, sCb; /* per-batch element strides (attention)                 */
   int32_t xf;            /* VAE_XF_*                                              */
   float alpha;           /* C = alpha * acc (+bias+res); 1.0 for conv             */
+  int32_t prec;          /* VAE_PREC_*: arithmetic of the products                */
 } vae_igemm_args;
 int vae_igemm_rows(const vae_igemm_args* a, void* stream);
 /* 1 when xf != NONE can be fused for this geometry (the GroupNorm scale/shift rows a tile needs are staged in
@@ -97,6 +104,7 @@ typedef struct vae_wgrad_args {
   int32_t batch; int64_t sYb, sXb, sOb;
   int32_t xf;
   float alpha;
+  int32_t prec;          /* VAE_PREC_* */
 } vae_wgrad_args;
 int vae_wgrad(const vae_wgrad_args* a, void* stream);
 /* split-K plan for `a` (a->nsplit ignored): the nsplit to launch with, and whether a->xf can be fused

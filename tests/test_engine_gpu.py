@@ -162,3 +162,35 @@ def test_standalone_submodule_calls(pair):
         assert _rel(r, ref) < 1e-4
         g = w.vae.encoder.down_blocks[0].resnets[0].norm1(t.cuda())
         assert _rel(g, o.vae.encoder.down_blocks[0].resnets[0].norm1(t)) < 1e-5
+
+
+def test_bf16_compute_mode_tracks_fp32(pair):
+    """training.mixed_precision: bf16 -- bf16 MFMA products with fp32 accumulation, fp32 tensors and statistics.
+    Tolerance is the arithmetic's (bf16 has 8 significant bits): losses 2e-2, gradient direction cosine > 0.99."""
+    import vae_oracle as vo
+    o, w = pair
+    R, B, klw = 64, 2, 1e-4
+    x, eps = vo.synthetic_pixels(B, R, 42, 5).cuda(), vo.synthetic_eps(B, R, 42, 5).cuda()
+    eng = w.vae.engine
+    names = ["encoder.down_blocks.0.resnets.0.norm1", "decoder.up_blocks.1.resnets.0.norm1"]
+    res, grads, stats = {}, {}, {}
+    for mode in ("no", "bf16"):
+        eng.set_precision(mode)
+        got = {}
+        hs = [eng.add_tracker(w.vae.get_submodule(n), "output", lambda v, n=n: got.__setitem__(n, v.cpu())) for n in names]
+        res[mode] = eng.forward_backward(x, eps, klw)["scalars"].cpu()
+        grads[mode] = w.vae.arena.grad.clone()
+        stats[mode] = got
+        for h in hs:
+            h.remove()
+    eng.set_precision("no")
+    assert float((res["bf16"] - res["no"]).abs().max() / res["no"].abs().max()) < 2e-2
+    assert not torch.equal(res["bf16"], res["no"])  # the bf16 kernels really ran
+    cos = torch.nn.functional.cosine_similarity(grads["bf16"].double(), grads["no"].double(), dim=0)
+    assert float(cos) > 0.99, float(cos)
+    gn = grads["bf16"].norm() / grads["no"].norm()
+    assert 0.97 < float(gn) < 1.03
+    for n in names:
+        assert float(((stats["bf16"][n] - stats["no"][n]).abs() / stats["no"][n]).max()) < 2e-2
+    with pytest.raises(NotImplementedError):
+        eng.set_precision("fp16")

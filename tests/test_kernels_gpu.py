@@ -284,3 +284,68 @@ def test_errors_are_loud(cuda):
     from vaehip.lib import lib
     with pytest.raises(VaeHipError):
         lib.call("vae_add", None, None, 0, None, None)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# bf16 compute mode (training.mixed_precision: bf16): operands rounded to bf16 at LDS staging, fp32 accumulate.
+# bf16 x bf16 products are exact in fp32, so against a CPU fp32 conv of the bf16-ROUNDED operands the kernel
+# must agree to summation-order accuracy -- a tight check of every index / transposing-read path.
+# ---------------------------------------------------------------------------------------------------------
+def _r16(t):
+    return t.bfloat16().float()
+
+
+@pytest.fixture
+def bf16_mode():
+    from vaehip import ops
+    ops.PRECISION = ops.PREC_BF16
+    yield
+    ops.PRECISION = ops.PREC_F32
+
+
+@pytest.mark.parametrize("kind,B,H,W,Ci,Co", [("c3", 2, 8, 32, 128, 128), ("c3", 1, 4, 64, 256, 512), ("c3", 2, 12, 32, 512, 256),
+                                              ("c3", 1, 4, 32, 96, 160), ("c3up", 2, 4, 16, 128, 256)])
+def test_bf16_conv_fwd_dgrad(cuda, bf16_mode, kind, B, H, W, Ci, Co):
+    from vaehip import ops
+    gen = torch.Generator().manual_seed(99 + Ci + Co)
+    x = torch.randn(B, Ci, H, W, generator=gen)
+    w = torch.randn(Co, Ci, 3, 3, generator=gen) / math.sqrt(Ci * 9)
+    b = torch.randn(Co, generator=gen)
+    xr = _r16(x).requires_grad_(True)
+    y_ref = _ref_conv(xr, _r16(w), b, kind)
+    dy = torch.randn(y_ref.shape, generator=gen)
+    y = ops.conv_fwd(_nhwc(x), _to_dev_ohwi(w), b.cuda(), kind)
+    assert _rel(_nchw(y), y_ref.detach()) < 2e-5
+    # dgrad: dY and W rounded to bf16
+    (gx,) = torch.autograd.grad(_ref_conv(xr, _r16(w), None, kind), xr, _r16(dy))
+    dx = ops.conv_dgrad(_nhwc(dy), _to_dev_ohwi(w), kind, (H, W))
+    assert _rel(_nchw(dx), gx) < 2e-5
+    # and the bf16 result is close to the true fp32 conv at bf16 accuracy
+    assert _rel(_nchw(y), _ref_conv(x, w, b, kind)) < 2e-2
+    # wgrad: dY and X rounded to bf16; bias gradient is summed in fp32 from the unrounded dY
+    if Ci % 64 == 0:
+        wr = w.clone().requires_grad_(True)
+        _ref_conv(_r16(x), wr, None, kind).backward(_r16(dy))
+        gw = torch.empty_like(_to_dev_ohwi(w).permute(0, 2, 3, 1).contiguous()).permute(0, 3, 1, 2)
+        gb = torch.empty(Co, device="cuda")
+        ops.conv_wgrad(_nhwc(dy), _nhwc(x), kind, gw, gb)
+        assert _rel(gw.cpu(), wr.grad) < 3e-5
+        assert _rel(gb.cpu(), dy.sum(dim=(0, 2, 3))) < 3e-5
+
+
+def test_bf16_conv_fused_gn_silu(cuda, bf16_mode):
+    from vaehip import ops
+    gen = torch.Generator().manual_seed(5)
+    B, C, H, W, Co = 2, 128, 8, 32, 256
+    x = torch.randn(B, C, H, W, generator=gen) * 1.3 + 0.2
+    gamma, beta = 1 + 0.3 * torch.randn(C, generator=gen), 0.2 * torch.randn(C, generator=gen)
+    w = torch.randn(Co, C, 3, 3, generator=gen) / math.sqrt(9 * C)
+    res = torch.randn(B, Co, H, W, generator=gen)
+    act = F.silu(F.group_norm(x, 32, gamma, beta, 1e-6))
+    y_ref = F.conv2d(_r16(act), _r16(w), None, 1, 1) + res
+    xd = _nhwc(x)
+    st = ops.gn_stats(xd, gamma.cuda(), beta.cuda())
+    y = ops.conv_fwd(xd, _to_dev_ohwi(w), None, "c3", xf=ops.XF_AFFINE_SILU, stats=st, res=_nhwc(res))
+    # rounding of the fp32 activation to bf16 can differ by one bf16 ulp where the GPU/CPU fp32 values differ in the
+    # last bit: allow a few 1e-4 of the output scale
+    assert _rel(_nchw(y), y_ref) < 5e-4

@@ -27,6 +27,8 @@ def timeit(fn, n=5):
 def main():
     names = sys.argv[1:] or list(SHAPES)
     only = os.environ.get("MB_ONLY", "")
+    if os.environ.get("MB_PREC", "f32") == "bf16":
+        ops.PRECISION = ops.PREC_BF16
     for nm in names:
         B, H, Ci, Co = SHAPES[nm]
         g = torch.Generator(device="cuda").manual_seed(0)

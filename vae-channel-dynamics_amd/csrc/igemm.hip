@@ -20,9 +20,14 @@
 
 bool conv3_tile_eligible(const vae_igemm_args& a, bool vec, bool bkm);
 int launch_conv3_tile(const vae_igemm_args& a, bool bkm, hipStream_t st);
+int launch_conv3_tile_bf16(const vae_igemm_args& a, bool bkm, hipStream_t st);
 bool wgrad3_tile_eligible(const vae_wgrad_args& a, bool vec);
 int64_t wgrad3_tile_units(const vae_conv_geom& g);
 int launch_wgrad3_tile(const vae_wgrad_args& a, hipStream_t st);
+bool wgrad3_tile_bf16_eligible(const vae_wgrad_args& a, bool vec);
+int64_t wgrad3_tile_bf16_units(const vae_conv_geom& g);
+int wgrad3_tile_bf16_columns(const vae_wgrad_args& a);
+int launch_wgrad3_tile_bf16(const vae_wgrad_args& a, hipStream_t st);
 
 namespace {
 
@@ -516,17 +521,37 @@ static bool wgrad_vec(const vae_wgrad_args& a) {
   return vec;
 }
 static bool wgrad_use_tile(const vae_wgrad_args& a) { return wgrad3_tile_eligible(a, wgrad_vec(a)) && !getenv("VAEHIP_FLAT_CONV"); }
+static bool wgrad_use_tile_bf16(const vae_wgrad_args& a) {
+  return a.prec == VAE_PREC_BF16 && wgrad3_tile_bf16_eligible(a, wgrad_vec(a)) && !getenv("VAEHIP_FLAT_CONV");
+}
 
 // split-K plan: which nsplit to use for these arguments (a->nsplit is ignored) and whether a->xf can be fused.
 // The caller allocates partial[nsplit][M*taps*N] (+ bias_partial[nsplit][M]) accordingly.
 extern "C" int vae_wgrad_plan(const vae_wgrad_args* ap, int32_t* nsplit, int32_t* xf_fusable) {
   VAE_CHECK(ap && nsplit && xf_fusable, "wgrad_plan: null argument");
   const vae_wgrad_args& a = *ap;
+  // a workgroup keeps the GroupNorm scale/shift rows of every batch item its unit range touches in LDS
+  // (SS_HALF entries): the split count is raised until that fits
+  auto min_split = [&](int64_t units, int ci_tile) -> int64_t {
+    if (a.xf == VAE_XF_NONE) return 1;
+    const int64_t upi = units / a.g.B;                         // units per image
+    const int64_t nb_max = SS_HALF / ci_tile;                  // batch items whose rows fit
+    const int64_t per_max = std::max<int64_t>(1, (nb_max - 1) * upi);
+    return (units + per_max - 1) / per_max;
+  };
+  if (wgrad_use_tile_bf16(a)) {
+    const int64_t units = wgrad3_tile_bf16_units(a.g);
+    const int64_t cols = wgrad3_tile_bf16_columns(a);
+    int64_t ns = std::max<int64_t>(1, std::min<int64_t>(512 / std::max<int64_t>(cols, 1), units / 4));
+    *nsplit = (int32_t)std::max(ns, min_split(units, 64));
+    *xf_fusable = 1;
+    return VAE_OK;
+  }
   if (wgrad_use_tile(a)) {
     const int64_t units = wgrad3_tile_units(a.g);
     const int64_t wgs = (int64_t)((a.M + 127) / 128) * (a.N / 32);
     int64_t ns = std::max<int64_t>(1, std::min<int64_t>(1024 / std::max<int64_t>(wgs, 1), units / 8));
-    *nsplit = (int32_t)ns;
+    *nsplit = (int32_t)std::max(ns, min_split(units, 32));
     *xf_fusable = 1;
     return VAE_OK;
   }
@@ -558,7 +583,8 @@ extern "C" int vae_igemm_kernel_name(const vae_igemm_args* ap, char* buf, int32_
   const bool bkm = rows_bkm(a), vec = rows_vec(a, bkm);
   const char* tf[2] = {"false", "true"};
   if (rows_use_tile(a, vec, bkm))
-    snprintf(buf, n, "conv3_tile_kernel<%s,%s,%s,%d>", tf[bkm], tf[a.g.mode == VAE_MODE_DGRAD], tf[a.g.mode == VAE_MODE_UP2X], a.xf);
+    snprintf(buf, n, "conv3_tile%s_kernel<%s,%s,%s,%d>", a.prec == VAE_PREC_BF16 ? "_bf16" : "", tf[bkm],
+             tf[a.g.mode == VAE_MODE_DGRAD], tf[a.g.mode == VAE_MODE_UP2X], a.xf);
   else if (a.N <= 32)
     snprintf(buf, n, "igemm_rows_kernel<128,32,4,1,%s,%s,%d>", tf[bkm], tf[vec], a.xf);
   else
@@ -570,7 +596,8 @@ extern "C" int vae_wgrad_kernel_name(const vae_wgrad_args* ap, char* buf, int32_
   const vae_wgrad_args& a = *ap;
   const bool vec = wgrad_vec(a);
   const char* tf[2] = {"false", "true"};
-  if (wgrad_use_tile(a)) snprintf(buf, n, "wgrad3_tile_kernel<%s,%d>", tf[a.g.mode == VAE_MODE_UP2X], a.xf);
+  if (wgrad_use_tile_bf16(a)) snprintf(buf, n, "wgrad3_tile_bf16_kernel<%s,%d>", tf[a.g.mode == VAE_MODE_UP2X], a.xf);
+  else if (wgrad_use_tile(a)) snprintf(buf, n, "wgrad3_tile_kernel<%s,%d>", tf[a.g.mode == VAE_MODE_UP2X], a.xf);
   else snprintf(buf, n, "wgrad_kernel<%s,%s,%d>", a.M <= 32 ? "32,128,1,4" : (a.N <= 32 ? "128,32,4,1" : "128,128,4,2"), tf[vec], a.xf);
   return VAE_OK;
 }
@@ -584,6 +611,7 @@ extern "C" int vae_igemm_rows(const vae_igemm_args* ap, void* stream) {
   VAE_CHECK(a.K <= a.g.Cs, "igemm_rows: K=%d exceeds source channels %d", a.K, a.g.Cs);
   VAE_CHECK((int64_t)a.g.B * a.g.Ho * a.g.Wo == a.M, "igemm_rows: M=%d != B*Ho*Wo", a.M);
   VAE_CHECK(a.ldc >= a.N, "igemm_rows: ldc < N");
+  VAE_CHECK(a.prec == VAE_PREC_F32 || a.prec == VAE_PREC_BF16, "igemm_rows: bad prec %d", a.prec);
   VAE_CHECK(a.sk == 1 || a.sn == 1, "igemm_rows: one of sn, sk must be 1 (sn=%lld sk=%lld)", (long long)a.sn,
             (long long)a.sk);
   VAE_CHECK(a.xf == VAE_XF_NONE || (a.scale && a.shift), "igemm_rows: xf needs scale/shift");
@@ -593,7 +621,7 @@ extern "C" int vae_igemm_rows(const vae_igemm_args* ap, void* stream) {
   const bool vec = rows_vec(a, bkm);
   hipStream_t st = (hipStream_t)stream;
   if (rows_use_tile(a, vec, bkm)) {  // 3x3 stride-1: LDS halo tile shared by the 9 taps
-    if (int rc2 = launch_conv3_tile(a, bkm, st)) return rc2;
+    if (int rc2 = (a.prec == VAE_PREC_BF16) ? launch_conv3_tile_bf16(a, bkm, st) : launch_conv3_tile(a, bkm, st)) return rc2;
     VAE_LAUNCH_CHECK("conv3_tile");
     return VAE_OK;
   }
@@ -618,6 +646,13 @@ extern "C" int vae_wgrad(const vae_wgrad_args* ap, void* stream) {
   VAE_CHECK(a.bias_partial == nullptr || a.batch == 1, "wgrad: bias_partial is for batch == 1 only");
   const bool vec = wgrad_vec(a);
   hipStream_t st = (hipStream_t)stream;
+  VAE_CHECK(a.prec == VAE_PREC_F32 || a.prec == VAE_PREC_BF16, "wgrad: bad prec %d", a.prec);
+  if (wgrad_use_tile_bf16(a)) {
+    VAE_CHECK(a.nsplit <= 65535, "wgrad: nsplit too large");
+    if (int rc2 = launch_wgrad3_tile_bf16(a, st)) return rc2;
+    VAE_LAUNCH_CHECK("wgrad3_tile_bf16");
+    return VAE_OK;
+  }
   if (wgrad_use_tile(a)) {  // 3x3 stride-1: the nine taps share one staged dY tile + X halo
     VAE_CHECK(a.nsplit <= 65535, "wgrad: nsplit too large");
     if (int rc2 = launch_wgrad3_tile(a, st)) return rc2;

@@ -196,7 +196,6 @@ bool wgrad3_tile_eligible(const vae_wgrad_args& a, bool vec) {
   if (g.mode == VAE_MODE_FWD && !(g.Ho == g.Hs && g.Wo == g.Ws)) return false;
   if (g.mode == VAE_MODE_UP2X && !(g.Ho == 2 * g.Hs && g.Wo == 2 * g.Ws)) return false;
   if (g.mode == VAE_MODE_DGRAD) return false;
-  if (a.xf != VAE_XF_NONE && (int64_t)g.B * BNT > SS_HALF) return false;
   return true;
 }
 

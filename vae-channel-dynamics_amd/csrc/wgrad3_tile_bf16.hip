@@ -1,0 +1,240 @@
+// bf16-compute weight gradient of a 3x3 stride-1 convolution (plain or over a virtual nearest-2x upsample):
+//   dW[co][tap][ci] = sum_{b,y,x} dY[b][y][x][co] * XF(X)[b][y+kh-1][x+kw-1][ci]
+// fp32 tensors in HBM, operands rounded to bf16 while staged in LDS (after the fp32 GroupNorm+SiLU), products
+// on v_mfma_f32_32x32x16_bf16, fp32 accumulation, fp32 split-K partial slabs (vae_reduce_splits sums them).
+//
+// Workgroup (12 waves) = 128 co x 64 ci x all 9 taps over a range of units; one unit = a 2x32-pixel output tile.
+// Per unit the dY tile [64 px][128 co] and the 4x34-pixel X halo [136 px][64 ci] are staged pixel-major (double
+// buffered)
+// (their memory order); since the contraction runs over pixels, both MFMA operands need 8 consecutive PIXELS
+// per lane, which the transposing LDS load (ds_read_b64_tr_b16) delivers from the pixel-major images.
+// Wave (mt, kh) owns co rows mt*32.. and filter row kh: 3 taps x 2 ci sub-tiles = 6 accumulators.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16;
+
+constexpr int TH = 2, TW = 32, UPX = TH * TW;   // 64 pixels per unit
+constexpr int HWD = TW + 2, HPX = (TH + 2) * HWD;  // 136 halo pixels
+constexpr int BMT = 128, BNT = 64;
+constexpr int LDA = BMT + 32;                   // dY image row stride (320 B: tr reads conflict-free)
+constexpr int LDH = BNT + 32;                   // halo image row stride (192 B)
+constexpr int SA = UPX * LDA, SH = HPX * LDH;   // u16 elements
+constexpr int STAGE = SA + SH;
+constexpr int NT = 768;
+constexpr int AQ = UPX * (BMT / 4);             // dY float4 slots (2048)
+constexpr int AI = (AQ + NT - 1) / NT;          // 3
+constexpr int HQ = HPX * (BNT / 4);             // halo float4 slots (2176)
+constexpr int HI = (HQ + NT - 1) / NT;          // 3
+
+__device__ __forceinline__ uint2 pack4(f32x4 v) {
+  bf16x4 h;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) h[e] = (__bf16)v[e];
+  return __builtin_bit_cast(uint2, h);
+}
+__device__ __forceinline__ bf16x8 frag_tr(const u16* p, int ld) {
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * ld));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+template <bool UP, int XF>
+__global__ __launch_bounds__(NT) void wgrad3_tile_bf16_kernel(vae_wgrad_args p, int tiles_x, int tiles_y, int64_t nunits) {
+  constexpr int SSB = (XF != VAE_XF_NONE) ? 2 * SS_HALF * 2 : 0;
+  __shared__ __attribute__((aligned(16))) u16 smem[2 * STAGE + SSB];
+  float* sS = reinterpret_cast<float*>(smem + 2 * STAGE);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int mt = wave & 3, tg = wave >> 2;  // co sub-tile, filter row kh
+  const int trq = (lane & 15) >> 2, trp = lane & 3, trh = (lane >> 4) & 1;
+  const vae_conv_geom g = p.g;
+  const int tilesN = p.N / BNT;
+  const int tm = blockIdx.x / tilesN, tn = blockIdx.x % tilesN;
+  const int m0 = tm * BMT, n0 = tn * BNT;
+  const int split = blockIdx.y;
+  const int64_t per = (nunits + p.nsplit - 1) / p.nsplit;
+  const int64_t ubeg = split * per, uend = min(nunits, ubeg + per);
+  const int nu = (int)max((int64_t)0, uend - ubeg);
+  const int Hb = UP ? 2 * g.Hs : g.Hs, Wb = UP ? 2 * g.Ws : g.Ws;
+  const bool do_bias = (p.bias_partial != nullptr) && tn == 0;
+  const int units_per_img = tiles_x * tiles_y;
+
+  const int b_lo = nu > 0 ? (int)(ubeg / units_per_img) : 0;
+  if (XF != VAE_XF_NONE && nu > 0) {
+    const int nb = (int)((uend - 1) / units_per_img) - b_lo + 1;
+    const int nent = min(nb * BNT, SS_HALF);
+    for (int i = tid; i < nent; i += NT) {
+      const int j = i / BNT, c = i - j * BNT;
+      sS[i] = p.scale[(int64_t)(b_lo + j) * g.Cs + n0 + c];
+      sS[SS_HALF + i] = p.shift[(int64_t)(b_lo + j) * g.Cs + n0 + c];
+    }
+  }
+
+  f32x16 acc[3][2];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][ni][r] = 0.f;
+
+  f32x4 ra[AI], rh[HI];
+  int hb = 0, hmask = 0;
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+  const int a4 = tid & 31;  // dY column quad (NT % 32 == 0: the same for every slot of this thread)
+
+  auto load_regs = [&](int64_t u) {
+    const int b = (int)(u / units_per_img);
+    const int rem = (int)(u - (int64_t)b * units_per_img);
+    const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+    const int y0 = ty * TH, x0 = tx * TW;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int q = tid + NT * i;
+      const int px = q >> 5;  // 0..63 : (row px>>5, col px&31)
+      const int64_t pix = ((int64_t)b * g.Ho + y0 + (px >> 5)) * g.Wo + x0 + (px & 31);
+      const int c = m0 + a4 * 4;
+      ra[i] = load4g<true>(p.dY + pix * p.ldy + c, q < AQ, p.dY, c, p.M);
+    }
+    hb = b;
+    hmask = 0;
+#pragma unroll
+    for (int i = 0; i < HI; ++i) {
+      const int q = tid + NT * i;
+      const int pp = q >> 4, k4 = q & 15;
+      const int ir = pp / HWD, jc = pp - ir * HWD;
+      const int hy = y0 - 1 + ir, hx = x0 - 1 + jc;
+      const bool ok = (q < HQ) && ((unsigned)hy < (unsigned)Hb) && ((unsigned)hx < (unsigned)Wb);
+      const int sy = UP ? (hy >> 1) : hy, sx = UP ? (hx >> 1) : hx;
+      const int c = n0 + k4 * 4;
+      rh[i] = load4g<true>(p.X + (((int64_t)b * g.Hs + sy) * g.Ws + sx) * g.Cs + c, ok, p.X, c, p.N);
+      hmask |= (ok ? 1 : 0) << i;
+    }
+  };
+  auto store_lds = [&](u16* sA, u16* sH) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int q = tid + NT * i;
+      if (q < AQ) {
+        *reinterpret_cast<uint2*>(&sA[(q >> 5) * LDA + a4 * 4]) = pack4(ra[i]);
+        if (do_bias) bsum += ra[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < HI; ++i) {
+      const int q = tid + NT * i;
+      if (q < HQ) {
+        f32x4 v = rh[i];
+        if (XF != VAE_XF_NONE) {
+          const bool ok = (hmask >> i) & 1;
+          const int o = ok ? (hb - b_lo) * BNT + (q & 15) * 4 : 0;
+          v = xform4_tab<XF>(v, sS + o, sS + SS_HALF + o, ok);
+        }
+        *reinterpret_cast<uint2*>(&sH[(q >> 4) * LDH + (q & 15) * 4]) = pack4(v);
+      }
+    }
+  };
+  auto compute = [&](const u16* sA, const u16* sH, int kg) {  // 16 consecutive pixels of tile row kg>>1
+    const int r = kg >> 1, c0 = (kg & 1) * 16;
+    const bf16x8 a = frag_tr(sA + (kg * 16 + lh * 8 + trq) * LDA + mt * 32 + trh * 16 + trp * 4, LDA);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {  // tap (kh = tg, kw = t): halo pixel (r + kh, c + kw)
+      const u16* hrow = sH + ((r + tg) * HWD + c0 + lh * 8 + trq + t) * LDH + trh * 16 + trp * 4;
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const bf16x8 bq = frag_tr(hrow + ni * 32, LDH);
+        acc[t][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, acc[t][ni], 0, 0, 0);
+      }
+    }
+  };
+
+  if (nu > 0) {
+    load_regs(ubeg);
+    __syncthreads();  // scale/shift table visible
+    store_lds(smem, smem + SA);
+    if (nu > 1) load_regs(ubeg + 1);
+    __syncthreads();
+    for (int s = 0; s < nu; ++s) {
+      const u16* cA = smem + (s & 1) * STAGE;
+      compute(cA, cA + SA, 0);
+      compute(cA, cA + SA, 1);
+      if (s + 1 < nu) {  // staged in the shadow of the MFMAs already issued
+        u16* nA = smem + ((s + 1) & 1) * STAGE;
+        store_lds(nA, nA + SA);
+        if (s + 2 < nu) load_regs(ubeg + s + 2);
+      }
+      compute(cA, cA + SA, 2);
+      compute(cA, cA + SA, 3);
+      __syncthreads();
+    }
+  }
+
+  const int64_t ld = (int64_t)9 * p.N;
+  float* __restrict__ O = (p.nsplit == 1 ? p.out : p.partial + (int64_t)split * p.M * ld);
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int tap = tg * 3 + t;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int col = n0 + ni * 32 + lr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < p.M) O[(int64_t)row * ld + (int64_t)tap * p.N + col] = p.alpha * acc[t][ni][r];
+      }
+    }
+  }
+  if (do_bias) {
+    f32x4* red = reinterpret_cast<f32x4*>(smem);  // [NT/32][32]
+    red[tid] = bsum;
+    __syncthreads();
+    if (tid < BMT / 4) {
+      f32x4 t4 = {0.f, 0.f, 0.f, 0.f};
+      for (int r = 0; r < NT / 32; ++r) t4 += red[r * 32 + tid];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = m0 + tid * 4 + e;
+        if (m < p.M) p.bias_partial[(int64_t)split * p.M + m] = t4[e];
+      }
+    }
+  }
+}
+
+}  // namespace
+
+bool wgrad3_tile_bf16_eligible(const vae_wgrad_args& a, bool vec) {
+  const vae_conv_geom& g = a.g;
+  if (!vec || a.batch != 1 || g.taps != 9 || g.stride != 1 || g.pad_t != 1 || g.pad_l != 1) return false;
+  if (a.M <= 32 || a.N % BNT != 0 || g.Wo % TW != 0 || g.Ho % TH != 0) return false;
+  if (g.mode == VAE_MODE_FWD && !(g.Ho == g.Hs && g.Wo == g.Ws)) return false;
+  if (g.mode == VAE_MODE_UP2X && !(g.Ho == 2 * g.Hs && g.Wo == 2 * g.Ws)) return false;
+  if (g.mode == VAE_MODE_DGRAD) return false;
+  return true;
+}
+int64_t wgrad3_tile_bf16_units(const vae_conv_geom& g) { return (int64_t)g.B * (g.Ho / TH) * (g.Wo / TW); }
+int wgrad3_tile_bf16_columns(const vae_wgrad_args& a) { return ((a.M + BMT - 1) / BMT) * (a.N / BNT); }
+
+int launch_wgrad3_tile_bf16(const vae_wgrad_args& a, hipStream_t st) {
+  const vae_conv_geom& g = a.g;
+  const int tx = g.Wo / TW, ty = g.Ho / TH;
+  const int64_t nunits = wgrad3_tile_bf16_units(g);
+  dim3 grid((unsigned)wgrad3_tile_bf16_columns(a), (unsigned)a.nsplit, 1);
+  const bool up = g.mode == VAE_MODE_UP2X;
+#define WG3(UPV, XFV) hipLaunchKernelGGL((wgrad3_tile_bf16_kernel<UPV, XFV>), grid, dim3(NT), 0, st, a, tx, ty, nunits)
+  switch (a.xf) {
+    case VAE_XF_NONE: if (up) WG3(true, VAE_XF_NONE); else WG3(false, VAE_XF_NONE); break;
+    case VAE_XF_AFFINE: if (up) WG3(true, VAE_XF_AFFINE); else WG3(false, VAE_XF_AFFINE); break;
+    default: if (up) WG3(true, VAE_XF_AFFINE_SILU); else WG3(false, VAE_XF_AFFINE_SILU); break;
+  }
+#undef WG3
+  return 0;
+}

@@ -41,6 +41,7 @@ class Engine:
         self.reducer = None  # optional DP bucket reducer with .ready(low_offset)
         self._low: Dict[int, int] = {}
         self._ident: Dict[tuple, Stats] = {}
+        self.precision = ops.PREC_F32  # arithmetic of the 3x3 conv contractions (set_precision)
 
     # ------------------------------------------------------------------ plumbing
     @property
@@ -50,6 +51,17 @@ class Engine:
     @property
     def arena(self):
         return self.vae.arena
+
+    def set_precision(self, mode) -> None:
+        """'no'/'fp32' (exact fp32 MFMA) or 'bf16' (operands rounded to bf16 in LDS, fp32 accumulate; tensors,
+        master weights and statistics stay fp32).  Mirrors training.mixed_precision of the reference's YAML."""
+        if mode in (None, "no", "fp32", torch.float32, ops.PREC_F32):
+            self.precision = ops.PREC_F32
+        elif mode in ("bf16", torch.bfloat16) or (mode == ops.PREC_BF16 and not isinstance(mode, bool)):
+            self.precision = ops.PREC_BF16
+        else:
+            raise NotImplementedError(f"mixed_precision={mode!r}: only 'no' and 'bf16' exist on this path "
+                                      "(fp16 needs loss scaling, which the reference does not configure either)")
 
     def _require_gpu(self):
         if self.arena.flat.device.type != "cuda":
@@ -332,22 +344,22 @@ class Engine:
         """fwd + loss (train.py:289-291) + bwd; gradients are WRITTEN into arena.grad (no accumulation).
         Returns dict(scalars[3]=mse,kl,total on device, reconstruction, moments, latents) as NHWC buffers."""
         self._require_gpu()
-        B, Cc, H, W = pixel_values.shape
         pv = pixel_values.contiguous()
-        x4 = ops.nchw_to_nhwc(pv, 4)
-        tgt = ops.nchw_to_nhwc(pv, 3)
-        te: list = []
-        td: list = []
-        mom = self.encode_nhwc(x4, te)
-        e = self._eps_nhwc(eps, mom, sample_posterior, generator)
-        z, klp = ops.sample_kl(mom, e)
-        recon = self.decode_nhwc(z, td)
-        scalars = ops.mse_kl_loss(recon, tgt, klp, kl_weight)
-        drec = ops.mse_bwd(recon, tgt)
-        self.arena.attach_grads()
-        dz = self.run_tape(td, drec, self.arena.grad)
-        dmom = ops.sample_kl_bwd(mom, e, dz, kl_weight)
-        self.run_tape(te, dmom, self.arena.grad)
+        with ops.precision(self.precision):
+            x4 = ops.nchw_to_nhwc(pv, 4)
+            tgt = ops.nchw_to_nhwc(pv, 3)
+            te: list = []
+            td: list = []
+            mom = self.encode_nhwc(x4, te)
+            e = self._eps_nhwc(eps, mom, sample_posterior, generator)
+            z, klp = ops.sample_kl(mom, e)
+            recon = self.decode_nhwc(z, td)
+            scalars = ops.mse_kl_loss(recon, tgt, klp, kl_weight)
+            drec = ops.mse_bwd(recon, tgt)
+            self.arena.attach_grads()
+            dz = self.run_tape(td, drec, self.arena.grad)
+            dmom = ops.sample_kl_bwd(mom, e, dz, kl_weight)
+            self.run_tape(te, dmom, self.arena.grad)
         if self.reducer is not None:
             self.reducer.ready(0)
         return {"scalars": scalars, "reconstruction": recon, "moments": mom, "latents": z, "kl_partial": klp}
@@ -359,10 +371,11 @@ class Engine:
         pv = pixel_values.contiguous()
         x4 = ops.nchw_to_nhwc(pv, 4)
         tgt = ops.nchw_to_nhwc(pv, 3)
-        mom = self.encode_nhwc(x4, None)
-        e = self._eps_nhwc(eps, mom, sample_posterior, generator)
-        z, klp = ops.sample_kl(mom, e)
-        recon = self.decode_nhwc(z, None)
+        with ops.precision(self.precision):
+            mom = self.encode_nhwc(x4, None)
+            e = self._eps_nhwc(eps, mom, sample_posterior, generator)
+            z, klp = ops.sample_kl(mom, e)
+            recon = self.decode_nhwc(z, None)
         scalars = ops.mse_kl_loss(recon, tgt, klp, kl_weight)
         return {"scalars": scalars, "reconstruction": recon, "moments": mom, "latents": z, "kl_partial": klp}
 
@@ -450,7 +463,8 @@ class _EncodeFn(torch.autograd.Function):
         need = record and any(p.requires_grad for p in params)
         tape = [] if need else None
         x4 = ops.nchw_to_nhwc(x.detach().to(dtype=torch.float32).contiguous(), 4)
-        mom = eng.encode_nhwc(x4, tape)
+        with ops.precision(eng.precision):
+            mom = eng.encode_nhwc(x4, tape)
         ctx.eng, ctx.tape, ctx.params = eng, tape, params
         return mom.permute(0, 3, 1, 2)
 
@@ -460,7 +474,8 @@ class _EncodeFn(torch.autograd.Function):
         if ctx.tape is None:
             raise RuntimeError("backward through a forward that recorded no tape")
         gbuf = torch.zeros_like(eng.arena.grad)
-        eng.run_tape(ctx.tape, dmom.permute(0, 2, 3, 1).contiguous(), gbuf)
+        with ops.precision(eng.precision):
+            eng.run_tape(ctx.tape, dmom.permute(0, 2, 3, 1).contiguous(), gbuf)
         grads = [eng.arena.grad_view(p, gbuf) if p.requires_grad else None for p in ctx.params]
         return (None, None, None, *grads)
 
@@ -471,7 +486,8 @@ class _DecodeFn(torch.autograd.Function):
         need = record and (z.requires_grad or any(p.requires_grad for p in params))
         tape = [] if need else None
         zz = z.detach().to(dtype=torch.float32).permute(0, 2, 3, 1).contiguous()
-        rec = eng.decode_nhwc(zz, tape)
+        with ops.precision(eng.precision):
+            rec = eng.decode_nhwc(zz, tape)
         ctx.eng, ctx.tape, ctx.params = eng, tape, params
         return rec.permute(0, 3, 1, 2)
 
@@ -481,6 +497,7 @@ class _DecodeFn(torch.autograd.Function):
         if ctx.tape is None:
             raise RuntimeError("backward through a forward that recorded no tape")
         gbuf = torch.zeros_like(eng.arena.grad)
-        dz = eng.run_tape(ctx.tape, drec.permute(0, 2, 3, 1).contiguous(), gbuf)
+        with ops.precision(eng.precision):
+            dz = eng.run_tape(ctx.tape, drec.permute(0, 2, 3, 1).contiguous(), gbuf)
         grads = [eng.arena.grad_view(p, gbuf) if p.requires_grad else None for p in ctx.params]
         return (None, None, dz.permute(0, 3, 1, 2), *grads)

@@ -12,6 +12,25 @@ import torch
 from .lib import ConvGeom, IgemmArgs, WgradArgs, lib
 
 XF_NONE, XF_AFFINE, XF_AFFINE_SILU = 0, 1, 2
+PREC_F32, PREC_BF16 = 0, 1
+# arithmetic of the conv contractions (set by the engine from training.mixed_precision); tensors stay fp32
+PRECISION = PREC_F32
+
+
+class precision:
+    """context manager: arithmetic of the conv contractions inside the block (PREC_F32 | PREC_BF16)"""
+
+    def __init__(self, prec: int):
+        self.prec = prec
+
+    def __enter__(self):
+        global PRECISION
+        self.prev, PRECISION = PRECISION, self.prec
+
+    def __exit__(self, *exc):
+        global PRECISION
+        PRECISION = self.prev
+        return False
 MODE_FWD, MODE_UP2X, MODE_DGRAD = 0, 1, 2
 GN_GROUPS = 32
 GN_EPS = 1e-6
@@ -154,7 +173,7 @@ def conv_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], kin
     a.M, a.N, a.K, a.ldc = B * g.Ho * g.Wo, Co, Ci, Co
     a.sn, a.sk, a.st = taps * Ci, 1, Ci
     a.batch, a.sAb, a.sWb, a.sCb = 1, 0, 0, 0
-    a.xf, a.alpha = xf, 1.0
+    a.xf, a.alpha, a.prec = xf, 1.0, PRECISION
     if track is not None:
         assert track.numel() >= ((a.M + 127) // 128) * Co
     _launch_igemm(a)
@@ -186,7 +205,7 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, kind: str, in_hw: Tuple[int, i
     a.M, a.N, a.K, a.ldc = B * Hr * Wr, Ci, Co, Ci
     a.sn, a.sk, a.st = 1, taps * Ci, Ci
     a.batch, a.sAb, a.sWb, a.sCb = 1, 0, 0, 0
-    a.xf, a.alpha = XF_NONE, 1.0
+    a.xf, a.alpha, a.prec = XF_NONE, 1.0, PRECISION
     _launch_igemm(a)
     if kind == "c3up":
         pooled = torch.empty((B, H, W, Ci), device=dy.device, dtype=torch.float32)
@@ -212,7 +231,7 @@ def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, kind: str, wgrad_out: torch.Te
     a.g = g
     a.M, a.N, a.ldy, a.npix, a.nsplit = Co, Ci, Co, npix, 1
     a.batch, a.sYb, a.sXb, a.sOb = 1, 0, 0, 0
-    a.xf, a.alpha = xf, 1.0
+    a.xf, a.alpha, a.prec = xf, 1.0, PRECISION
     if xf != XF_NONE:
         assert stats is not None
         a.scale, a.shift = _p(stats.scale), _p(stats.shift)

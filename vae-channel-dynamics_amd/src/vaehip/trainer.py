@@ -24,11 +24,12 @@ def lr_lambda_factory(warmup: int, max_steps: int) -> Callable[[int], float]:
 class HipTrainer:
     def __init__(self, wrapper, *, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=1.0,
                  kl_weight=1e-6, lr_warmup_steps=100, max_train_steps=1000, scheduler_steps_per_update: int = 1,
-                 bucket_mb: float = 64.0, generator: Optional[torch.Generator] = None):
+                 bucket_mb: float = 64.0, generator: Optional[torch.Generator] = None, mixed_precision: str = "no"):
         self.wrapper = wrapper
         self.vae = wrapper.vae
         self.kl_weight = float(kl_weight)
         self.generator = generator
+        self.vae.engine.set_precision(mixed_precision)
         self.optimizer = FusedAdamW(self.vae, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
                                     max_grad_norm=max_grad_norm)
         self.lr_scheduler = torch.optim.lr_scheduler.LambdaLR(self.optimizer, lr_lambda_factory(lr_warmup_steps, max_train_steps))
