@@ -47,7 +47,9 @@ def _oracle_step(o, x, eps, klw):
     return out, rec, kl, total, stats
 
 
-@pytest.mark.parametrize("R,B,klw", [(32, 2, 1e-6), (64, 2, 1e-2)])
+# (32,2) and (64,2): halo-tile kernels on the wide layers; (40,1) and (48,3): ragged sizes -- widths 40/20/10/5 and
+# 48/24/12/6 are no multiple of the 32-pixel tile, batch 1 / odd batch, attention over 25 / 36 tokens: flat kernels
+@pytest.mark.parametrize("R,B,klw", [(32, 2, 1e-6), (64, 2, 1e-2), (40, 1, 1e-4), (48, 3, 1e-3)])
 def test_forward_backward_matches_oracle(pair, R, B, klw):
     import vae_oracle as vo
     o, w = pair
