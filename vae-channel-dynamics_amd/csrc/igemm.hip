@@ -550,7 +550,7 @@ extern "C" int vae_wgrad_plan(const vae_wgrad_args* ap, int32_t* nsplit, int32_t
   if (wgrad_use_tile(a)) {
     const int64_t units = wgrad3_tile_units(a.g);
     const int64_t wgs = (int64_t)((a.M + 127) / 128) * (a.N / 32);
-    int64_t ns = std::max<int64_t>(1, std::min<int64_t>(1024 / std::max<int64_t>(wgs, 1), units / 8));
+    int64_t ns = std::max<int64_t>(1, std::min<int64_t>(512 / std::max<int64_t>(wgs, 1), units / 8));  // 2 rounds of 256 CUs
     *nsplit = (int32_t)std::max(ns, min_split(units, 32));
     *xf_fusable = 1;
     return VAE_OK;

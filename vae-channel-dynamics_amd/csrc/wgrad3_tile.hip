@@ -4,10 +4,9 @@
 //   dW[co][tap][ci] = sum_{b,y,x} dY[b][y][x][co] * XF(X)[b][y+kh-1][x+kw-1][ci]
 //
 // Workgroup (12 waves) = 128 output channels (co) x 32 input channels (ci) x ALL 9 taps, over a range of
-// "units" (one unit = 32 consecutive output pixels of one image row).  Per unit it stages dY[32 px][128 co]
-// and the 3x34-pixel halo of X (GroupNorm+SiLU applied while staging): 29 KB per 576 MFMAs, against
-// 32 KB per 256 MFMAs for the flat kernel (igemm.hip wgrad_kernel), and the activation is transformed 3x
-// instead of 9x per co-tile.  Wave w owns co rows (w&3)*32.. and the three taps of filter row kh = w>>2: its dY
+// "units" (one unit = a 2x32-pixel output tile).  Per unit it stages dY[64 px][128 co] and the 4x34-pixel
+// halo of X (GroupNorm+SiLU applied while staging): 52 KB per 1152 MFMAs, against 32 KB per 256 MFMAs for
+// the flat kernel (igemm.hip wgrad_kernel), and the activation is transformed 2.1x instead of 9x per co-tile.  Wave w owns co rows (w&3)*32.. and the three taps of filter row kh = w>>2: its dY
 // fragment is read once per 8-pixel group and reused for its 3 taps (3 accumulators = 48 VGPRs).  Both LDS tiles are pixel-major, so a
 // fragment read is one conflict-free ds_read_b32 per k.  LDS is double buffered, one barrier per unit.
 // Split-K over unit ranges; partial slabs are summed in fixed order by vae_reduce_splits (deterministic).
@@ -15,23 +14,25 @@
 
 namespace {
 
-constexpr int UPX = 32;                 // pixels per unit
+constexpr int TH = 2, TW = 32;          // unit = TH x TW output pixels
+constexpr int UPX = TH * TW;            // pixels per unit (64)
 constexpr int BMT = 128, BNT = 32;      // co tile, ci tile
 constexpr int LDA = BMT + 4;            // dY stage row stride (floats)
-constexpr int HWD = UPX + 2;            // halo width (34)
-constexpr int HPX = 3 * HWD;            // halo pixels (102)
+constexpr int HWD = TW + 2;             // halo width (34)
+constexpr int HPX = (TH + 2) * HWD;     // halo pixels (136)
 constexpr int LDH = BNT + 4;            // halo stage row stride
 constexpr int SA = UPX * LDA;           // 4224 floats
 constexpr int SH = HPX * LDH;           // 3672 floats
 constexpr int STAGE = SA + SH;
 constexpr int NT = 768;                                    // 12 waves: 4 co sub-tiles x 3 filter rows
-constexpr int AQ = UPX * (BMT / 4);                        // dY float4 slots (1024)
+constexpr int AQ = UPX * (BMT / 4);                        // dY float4 slots (2048)
 constexpr int AI = (AQ + NT - 1) / NT;                     // 2
-constexpr int HQ = HPX * (BNT / 4);                        // halo float4 slots (816)
+constexpr int HQ = HPX * (BNT / 4);                        // halo float4 slots (1088)
 constexpr int HI = (HQ + NT - 1) / NT;                     // 2
 
 template <bool UP, int XF>
 __global__ __launch_bounds__(NT) void wgrad3_tile_kernel(vae_wgrad_args p, int xblocks, int64_t nunits) {
+  // unit u -> (image b, tile row ty = 0..Ho/TH-1, x block xb)
   constexpr int SS = (XF != VAE_XF_NONE) ? 2 * SS_HALF : 0;
   __shared__ __attribute__((aligned(16))) float smem[2 * STAGE + SS];
   float* sS = smem + 2 * STAGE;
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(NT) void wgrad3_tile_kernel(vae_wgrad_args p, int x
   const int nu = (int)max((int64_t)0, uend - ubeg);
   const int Hb = UP ? 2 * g.Hs : g.Hs, Wb = UP ? 2 * g.Ws : g.Ws;
   const bool do_bias = (p.bias_partial != nullptr) && tn == 0;
-  const int rows_per_img = g.Ho * xblocks;  // units per image
+  const int rows_per_img = (g.Ho / TH) * xblocks;  // units per image
 
   const int b_lo = nu > 0 ? (int)(ubeg / rows_per_img) : 0;
   if (XF != VAE_XF_NONE && nu > 0) {
@@ -77,14 +78,15 @@ __global__ __launch_bounds__(NT) void wgrad3_tile_kernel(vae_wgrad_args p, int x
   auto load_regs = [&](int64_t u) {
     const int b = (int)(u / rows_per_img);
     const int rem = (int)(u - (int64_t)b * rows_per_img);
-    const int y = rem / xblocks, xb = rem - y * xblocks;
-    const int64_t pix0 = ((int64_t)b * g.Ho + y) * g.Wo + xb * UPX;
+    const int ty = rem / xblocks, xb = rem - ty * xblocks;
+    const int y = ty * TH;  // first output row of the unit
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       const int q = tid + NT * i;
-      const int k = q >> 5;
+      const int k = q >> 5;  // pixel of the unit: (row k / TW, col k % TW)
+      const int64_t pix = ((int64_t)b * g.Ho + y + k / TW) * g.Wo + xb * TW + (k % TW);
       const int c = m0 + a4 * 4;
-      ra[i] = load4g<true>(p.dY + (pix0 + k) * p.ldy + c, q < AQ, p.dY, c, p.M);
+      ra[i] = load4g<true>(p.dY + pix * p.ldy + c, q < AQ, p.dY, c, p.M);
     }
     hb = b;
     hmask = 0;
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(NT) void wgrad3_tile_kernel(vae_wgrad_args p, int x
       const int q = tid + NT * i;
       const int pp = q >> 3, k4 = q & 7;
       const int ir = pp / HWD, jc = pp - ir * HWD;
-      const int hy = y - 1 + ir, hx = xb * UPX - 1 + jc;
+      const int hy = y - 1 + ir, hx = xb * TW - 1 + jc;
       const bool ok = (q < HQ) && ((unsigned)hy < (unsigned)Hb) && ((unsigned)hx < (unsigned)Wb);
       const int sy = UP ? (hy >> 1) : hy, sx = UP ? (hx >> 1) : hx;
       const int c = n0 + k4 * 4;
@@ -124,15 +126,16 @@ __global__ __launch_bounds__(NT) void wgrad3_tile_kernel(vae_wgrad_args p, int x
       }
     }
   };
-  auto compute = [&](const float* sA, const float* sH, int kk) {
+  auto compute = [&](const float* sA, const float* sH, int kk) {  // 8 pixels of unit row kk / 4
+    const int r = kk / (TW / 8), c0 = (kk % (TW / 8)) * 8;
     float a[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) a[j] = sA[(kk * 8 + lh * 4 + j) * LDA + mt * 32 + lr];
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {  // tap (kh = tg, kw = t)
+    for (int t = 0; t < 3; ++t) {  // tap (kh = tg, kw = t): halo pixel (r + kh, c + kw)
       float bq[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bq[j] = sH[(tg * HWD + kk * 8 + lh * 4 + j + t) * LDH + lr];
+      for (int j = 0; j < 4; ++j) bq[j] = sH[((r + tg) * HWD + c0 + lh * 4 + j + t) * LDH + lr];
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bq[j], acc[t], 0, 0, 0);
     }
@@ -146,15 +149,15 @@ __global__ __launch_bounds__(NT) void wgrad3_tile_kernel(vae_wgrad_args p, int x
     __syncthreads();
     for (int s = 0; s < nu; ++s) {
       const float* cA = smem + (s & 1) * STAGE;
-      compute(cA, cA + SA, 0);
-      compute(cA, cA + SA, 1);
+#pragma unroll
+      for (int kk = 0; kk < UPX / 16; ++kk) compute(cA, cA + SA, kk);
       if (s + 1 < nu) {  // staged in the shadow of the MFMAs already issued
         float* nA = smem + ((s + 1) & 1) * STAGE;
         store_lds(nA, nA + SA);
         if (s + 2 < nu) load_regs(ubeg + s + 2);
       }
-      compute(cA, cA + SA, 2);
-      compute(cA, cA + SA, 3);
+#pragma unroll
+      for (int kk = UPX / 16; kk < UPX / 8; ++kk) compute(cA, cA + SA, kk);
       __syncthreads();
     }
   }
@@ -192,18 +195,18 @@ __global__ __launch_bounds__(NT) void wgrad3_tile_kernel(vae_wgrad_args p, int x
 bool wgrad3_tile_eligible(const vae_wgrad_args& a, bool vec) {
   const vae_conv_geom& g = a.g;
   if (!vec || a.batch != 1 || g.taps != 9 || g.stride != 1 || g.pad_t != 1 || g.pad_l != 1) return false;
-  if (a.M <= 32 || a.N % BNT != 0 || g.Wo % UPX != 0) return false;
+  if (a.M <= 32 || a.N % BNT != 0 || g.Wo % TW != 0 || g.Ho % TH != 0) return false;
   if (g.mode == VAE_MODE_FWD && !(g.Ho == g.Hs && g.Wo == g.Ws)) return false;
   if (g.mode == VAE_MODE_UP2X && !(g.Ho == 2 * g.Hs && g.Wo == 2 * g.Ws)) return false;
   if (g.mode == VAE_MODE_DGRAD) return false;
   return true;
 }
 
-int64_t wgrad3_tile_units(const vae_conv_geom& g) { return (int64_t)g.B * g.Ho * (g.Wo / UPX); }
+int64_t wgrad3_tile_units(const vae_conv_geom& g) { return (int64_t)g.B * (g.Ho / TH) * (g.Wo / TW); }
 
 int launch_wgrad3_tile(const vae_wgrad_args& a, hipStream_t st) {
   const vae_conv_geom& g = a.g;
-  const int xblocks = g.Wo / UPX;
+  const int xblocks = g.Wo / TW;
   const int64_t nunits = wgrad3_tile_units(g);
   dim3 grid((unsigned)(((a.M + BMT - 1) / BMT) * (a.N / BNT)), (unsigned)a.nsplit, 1);
   const bool up = g.mode == VAE_MODE_UP2X;
