@@ -49,6 +49,10 @@ int vae_abi_version(void);
 #define VAE_MODE_FWD 0   /* sy = y*stride + kh - pad_t                          */
 #define VAE_MODE_UP2X 1  /* source is virtually nearest-upsampled 2x, 3x3 pad 1 */
 #define VAE_MODE_DGRAD 2 /* sy = (y + pad_t - kh)/stride when divisible         */
+#define VAE_MODE_DGRAD_S2 3 /* dgrad of a 3x3 stride-2 pad-0 conv with the rows (= conv input pixels, Ho x Wo even)
+                             * enumerated PARITY-CLASS-major: m = ((cls*B + b)*Ho/2 + i)*Wo/2 + j, pixel (2i+cls/2, 2j+cls%2).
+                             * A class only meets the taps of its parity (4, 2, 2 or 1 of the 9), so no masked work;
+                             * needs B*Ho*Wo/4 % 128 == 0 (class-uniform tiles).  Output rows are written at the pixel. */
 
 typedef struct vae_conv_geom {
   int32_t B, Hs, Ws, Cs; /* source tensor [B][Hs][Ws][Cs]                         */

@@ -55,6 +55,8 @@ CONV_CASES = [
     ("c1", 2, 4, 4, 4, 4),          # post_quant_conv
     ("c3s2", 2, 16, 16, 128, 128),  # downsampler
     ("c3s2", 1, 10, 14, 128, 128),
+    ("c3s2", 2, 32, 32, 128, 128),  # B*H*W/4 % 128 == 0: parity-class-major dgrad (VAE_MODE_DGRAD_S2)
+    ("c3s2", 1, 16, 64, 256, 256),
     ("c3up", 2, 8, 8, 128, 128),    # upsampler
     ("c3up", 1, 5, 6, 256, 256),
     # shapes served by the LDS halo-tile kernel (W % 32 == 0, H % 4 == 0, Cout > 32)

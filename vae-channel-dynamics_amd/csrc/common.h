@@ -52,6 +52,10 @@ __device__ __forceinline__ bool src_pixel(const vae_conv_geom& g, int y, int x, 
     sy = uy >> 1;
     sx = ux >> 1;
     return ok;
+  } else if (g.mode == VAE_MODE_DGRAD_S2) {  // (y - kh, x - kw) are even by construction of the class tap list
+    sy = (y - kh) >> 1;
+    sx = (x - kw) >> 1;
+    return ((unsigned)sy < (unsigned)g.Hs) && ((unsigned)sx < (unsigned)g.Ws);
   } else {
     int ty = y + g.pad_t - kh, tx = x + g.pad_l - kw;
     if (ty < 0 || tx < 0) return false;

@@ -71,6 +71,30 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_rows_kernel(vae_igemm_args
   const float* __restrict__ W = p.W + (int64_t)z * p.sWb;
   const int hw = g.Ho * g.Wo;
 
+  // stride-2 dgrad, parity-class-major rows: the tile's class fixes the taps it meets
+  const bool s2c = (g.mode == VAE_MODE_DGRAD_S2);
+  const int hh = g.Ho >> 1, wh = g.Wo >> 1;
+  const int cls_rows = s2c ? p.M >> 2 : 1;
+  const int cls = s2c ? m0 / cls_rows : 0;
+  const int cpy = cls >> 1, cpx = cls & 1;
+  const int nkw = s2c ? (cpx ? 1 : 2) : 3;
+  const int ntaps = s2c ? (cpy ? 1 : 2) * nkw : g.taps;
+  auto row_pixel = [&](int m, int& b, int& y, int& x) {  // GEMM row -> (image, y, x) of the row grid
+    if (s2c) {
+      const int r = m - cls * cls_rows;
+      b = r / (hh * wh);
+      const int rem = r - b * (hh * wh);
+      const int i = rem / wh;
+      y = 2 * i + cpy;
+      x = 2 * (rem - i * wh) + cpx;
+    } else {
+      b = m / hw;
+      const int rem = m - b * hw;
+      y = rem / g.Wo;
+      x = rem - y * g.Wo;
+    }
+  };
+
   // per-thread A rows
   const int k4 = lt & 7, r0 = lt >> 3;
   int rb[AR], ry[AR], rx[AR];
@@ -78,9 +102,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_rows_kernel(vae_igemm_args
   for (int i = 0; i < AR; ++i) {
     int m = m0 + r0 + RP * i;
     if (m < p.M) {
-      int b = m / hw, rem = m - b * hw;
-      int y = rem / g.Wo;
-      rb[i] = b; ry[i] = y; rx[i] = rem - y * g.Wo;
+      row_pixel(m, rb[i], ry[i], rx[i]);
     } else {
       rb[i] = -1; ry[i] = 0; rx[i] = 0;
     }
@@ -108,17 +130,26 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_rows_kernel(vae_igemm_args
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
   const int kchunks = (p.K + BK - 1) / BK;
-  const int steps = g.taps * kchunks;
+  const int steps = ntaps * kchunks;
 
   f32x4 ra[AR], rbw[BR];
   int a_b[AR];  // batch index of the loaded row (for scale/shift), -1 = padding
   int reg_c0 = 0;
 
   auto load_regs = [&](int s) {
-    const int tap = s / kchunks;
-    const int c0 = (s - tap * kchunks) * BK;
+    const int ord = s / kchunks;  // ordinal of the tap among the taps this tile meets
+    const int c0 = (s - ord * kchunks) * BK;
     reg_c0 = c0;
-    const int kh = (g.taps == 9) ? tap / 3 : 0, kw = (g.taps == 9) ? tap - kh * 3 : 0;
+    int kh, kw;
+    if (s2c) {
+      const int a = ord / nkw;
+      kh = cpy ? 1 : 2 * a;
+      kw = cpx ? 1 : 2 * (ord - a * nkw);
+    } else {
+      kh = (g.taps == 9) ? ord / 3 : 0;
+      kw = (g.taps == 9) ? ord - kh * 3 : 0;
+    }
+    const int tap = kh * 3 + kw;
     const int c = c0 + k4 * 4;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
@@ -233,7 +264,13 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_rows_kernel(vae_igemm_args
         const int row = m0 + wm * TM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (colok && row < p.M) {
           float v = p.alpha * acc[mi][ni][r] + bv;
-          const int64_t o = (int64_t)row * p.ldc + col;
+          int64_t orow = row;
+          if (s2c) {  // class-major row -> pixel-major output row
+            int b, y, x;
+            row_pixel(row, b, y, x);
+            orow = ((int64_t)b * g.Ho + y) * g.Wo + x;
+          }
+          const int64_t o = orow * p.ldc + col;
           if (R) v += R[o];
           C[o] = v;
           tsum[ni] += fabsf(v);
@@ -492,7 +529,11 @@ int check_geom(const char* who, const vae_conv_geom& g) {
   VAE_CHECK(g.B > 0 && g.Hs > 0 && g.Ws > 0 && g.Cs > 0 && g.Ho > 0 && g.Wo > 0, "%s: non-positive geometry", who);
   VAE_CHECK(g.taps == 1 || g.taps == 9, "%s: taps must be 1 or 9 (got %d)", who, g.taps);
   VAE_CHECK(g.stride == 1 || g.stride == 2, "%s: stride must be 1 or 2", who);
-  VAE_CHECK(g.mode >= 0 && g.mode <= 2, "%s: bad mode", who);
+  VAE_CHECK(g.mode >= 0 && g.mode <= 3, "%s: bad mode", who);
+  VAE_CHECK(g.mode != VAE_MODE_DGRAD_S2 ||
+                (g.taps == 9 && g.stride == 2 && g.pad_t == 0 && g.pad_l == 0 && g.Ho % 2 == 0 && g.Wo % 2 == 0 &&
+                 ((int64_t)g.B * g.Ho * g.Wo / 4) % 128 == 0),
+            "%s: DGRAD_S2 needs 3x3 stride 2 pad 0, even row grid and B*Ho*Wo/4 %% 128 == 0", who);
   VAE_CHECK(g.mode != VAE_MODE_UP2X || (g.taps == 9 && g.stride == 1), "%s: up2x needs 3x3 stride 1", who);
   return 0;
 }
@@ -640,7 +681,7 @@ extern "C" int vae_wgrad(const vae_wgrad_args* ap, void* stream) {
   VAE_CHECK(a.N <= a.g.Cs, "wgrad: N exceeds source channels");
   VAE_CHECK((int64_t)a.g.B * a.g.Ho * a.g.Wo == a.npix, "wgrad: npix != B*Ho*Wo");
   VAE_CHECK(a.ldy >= a.M, "wgrad: ldy < M");
-  VAE_CHECK(a.g.mode != VAE_MODE_DGRAD, "wgrad: dgrad geometry not valid here");
+  VAE_CHECK(a.g.mode != VAE_MODE_DGRAD && a.g.mode != VAE_MODE_DGRAD_S2, "wgrad: dgrad geometry not valid here");
   VAE_CHECK(a.nsplit == 1 ? a.out != nullptr : a.partial != nullptr, "wgrad: missing output buffer");
   VAE_CHECK(a.xf == VAE_XF_NONE || (a.scale && a.shift), "wgrad: xf needs scale/shift");
   VAE_CHECK(a.bias_partial == nullptr || a.batch == 1, "wgrad: bias_partial is for batch == 1 only");
