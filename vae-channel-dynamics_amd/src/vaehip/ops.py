@@ -265,9 +265,12 @@ def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, kind: str, wgrad_out: torch.Te
 
 
 # ------------------------------------------------------------------ GroupNorm
+_GN_TARGET = 1024  # workgroups per GroupNorm streaming pass (B * nchunk); tools/gn_bench.py: best of 256..4096 on MI355X
+
+
 def _gn_nchunk(B: int, HW: int, Cc: int) -> int:
     pr = max(1, 256 // (Cc // 4))
-    return max(1, min(2048 // max(B, 1), HW // (16 * pr) if HW >= 16 * pr else 1))
+    return max(1, min(_GN_TARGET // max(B, 1), HW // (16 * pr) if HW >= 16 * pr else 1))
 
 
 def gn_stats(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, G: int = GN_GROUPS, eps: float = GN_EPS) -> Stats:
