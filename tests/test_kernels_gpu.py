@@ -351,3 +351,72 @@ def test_bf16_conv_fused_gn_silu(cuda, bf16_mode):
     # rounding of the fp32 activation to bf16 can differ by one bf16 ulp where the GPU/CPU fp32 values differ in the
     # last bit: allow a few 1e-4 of the output scale
     assert _rel(_nchw(y), y_ref) < 5e-4
+
+
+# shapes the bf16 FLAT kernels serve (igemm_bf16.hip): 1x1, stride 2 (gather dgrad and parity-class dgrad), ragged and
+# tiny 3x3, skinny N / skinny M, K tails that are not a multiple of the 64-channel step
+BF16_FLAT_CASES = [
+    ("c1", 2, 8, 8, 128, 256), ("c1", 2, 4, 4, 8, 8), ("c1", 1, 6, 10, 320, 96),
+    ("c3s2", 2, 16, 16, 128, 128), ("c3s2", 1, 10, 14, 128, 128), ("c3s2", 2, 32, 32, 128, 128), ("c3s2", 1, 16, 64, 256, 256),
+    ("c3", 2, 5, 7, 256, 128), ("c3", 2, 8, 8, 128, 128), ("c3", 2, 4, 4, 512, 8), ("c3", 2, 4, 4, 4, 512),
+    ("c3", 2, 16, 16, 128, 3), ("c3up", 1, 5, 6, 256, 256), ("c3", 1, 9, 5, 100, 36),
+]
+
+
+@pytest.mark.parametrize("kind,B,H,W,Ci,Co", BF16_FLAT_CASES)
+def test_bf16_flat_conv_fwd_dgrad_wgrad(cuda, bf16_mode, kind, B, H, W, Ci, Co):
+    from vaehip import ops
+    gen = torch.Generator().manual_seed(7 + Ci + Co + H)
+    k = 1 if kind == "c1" else 3
+    x = torch.randn(B, Ci, H, W, generator=gen)
+    w = torch.randn(Co, Ci, k, k, generator=gen) / math.sqrt(Ci * k * k)
+    b = torch.randn(Co, generator=gen)
+    wd = _to_dev_ohwi(w)
+    prof = ops.PROFILER = ops.LaunchProfiler()
+    try:
+        y = ops.conv_fwd(_nhwc(x), wd, b.cuda(), kind)
+        dy = torch.randn(y.permute(0, 3, 1, 2).shape, generator=gen)
+        dx = ops.conv_dgrad(_nhwc(dy), wd, kind, (H, W))
+        gw = torch.full_like(wd.permute(0, 2, 3, 1).contiguous(), float("nan")).permute(0, 3, 1, 2)
+        gb = torch.full((Co,), float("nan"), device="cuda")
+        ops.conv_wgrad(_nhwc(dy), _nhwc(x), kind, gw, gb)
+    finally:
+        ops.PROFILER = None
+    names = [r[0] for r in prof.records]
+    assert len(names) == 3
+    # channel counts that are not a multiple of 4 have no vectorised form and stay on the exact fp32 kernels
+    expect16 = [Ci % 4 == 0, Co % 4 == 0 and Ci % 4 == 0, Co % 4 == 0 and Ci % 4 == 0]
+    assert [("bf16" in n) for n in names] == expect16, names
+    rf, rd, rw = [(_r16 if e else (lambda t: t)) for e in expect16]
+    assert _rel(_nchw(y), _ref_conv(rf(x), rf(w), b, kind)) < 2e-5
+    xr = x.clone().requires_grad_(True)
+    (gx,) = torch.autograd.grad(_ref_conv(xr, rd(w), None, kind), xr, rd(dy))
+    assert _rel(_nchw(dx), gx) < 2e-5
+    wr = w.clone().requires_grad_(True)
+    _ref_conv(rw(x), wr, None, kind).backward(rw(dy))
+    assert _rel(gw.cpu(), wr.grad) < 3e-5
+    assert _rel(gb.cpu(), dy.sum(dim=(0, 2, 3))) < 3e-5  # bias gradient: fp32 sums of the unrounded dY on either path
+
+
+@pytest.mark.parametrize("C,H,W,silu", [(128, 16, 16, True), (512, 4, 4, True), (512, 6, 10, False)])
+def test_bf16_flat_fused_gn(cuda, bf16_mode, C, H, W, silu):
+    """GroupNorm(+SiLU) fused into the bf16 flat rows / wgrad kernels (1x1 and small 3x3)."""
+    from vaehip import ops
+    gen = torch.Generator().manual_seed(11 + C)
+    B, Co = 2, 128
+    x = torch.randn(B, C, H, W, generator=gen) * 1.3 + 0.2
+    gamma, beta = 1 + 0.3 * torch.randn(C, generator=gen), 0.2 * torch.randn(C, generator=gen)
+    w = torch.randn(Co, C, 3, 3, generator=gen) / math.sqrt(9 * C)
+    act = F.group_norm(x, 32, gamma, beta, 1e-6)
+    act = F.silu(act) if silu else act
+    xf = ops.XF_AFFINE_SILU if silu else ops.XF_AFFINE
+    xd = _nhwc(x)
+    st = ops.gn_stats(xd, gamma.cuda(), beta.cuda())
+    y = ops.conv_fwd(xd, _to_dev_ohwi(w), None, "c3", xf=xf, stats=st)
+    assert _rel(_nchw(y), F.conv2d(_r16(act), _r16(w), None, 1, 1)) < 5e-4
+    dy = torch.randn(B, Co, H, W, generator=gen)
+    wr = w.clone().requires_grad_(True)
+    F.conv2d(_r16(act), wr, None, 1, 1).backward(_r16(dy))
+    gw = torch.empty_like(_to_dev_ohwi(w).permute(0, 2, 3, 1).contiguous()).permute(0, 3, 1, 2)
+    ops.conv_wgrad(_nhwc(dy), xd, "c3", gw, None, xf=xf, stats=st)
+    assert _rel(gw.cpu(), wr.grad) < 5e-4

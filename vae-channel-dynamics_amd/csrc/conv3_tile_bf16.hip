@@ -7,14 +7,10 @@
 // one staged halo; the channel chunk is 64 (8 MFMAs per wave per barrier).  Forward reads both operands as
 // 16-byte k-contiguous fragments; dgrad keeps the weight tile in its memory order ([k = co][n = ci]) and reads
 // it with the transposing LDS load (ds_read_b64_tr_b16).
-#include "common.h"
+#include "bf16_frag.h"
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef unsigned short u16;
 
 constexpr int BK = 64, TH = 4, TW = 32, HW_ = TW + 2, HP = (TH + 2) * HW_;  // 204 halo pixels
 constexpr int LDH = BK + 8;                 // halo row stride in bf16 (144 B: conflict-free ds_read_b128)
@@ -25,25 +21,6 @@ constexpr int HI = (HQ + NT - 1) / NT;      // 7
 constexpr int LDBK = BK + 8;                // weight tile [n][k] row stride (forward)
 constexpr int LDBN = BN + 32;               // weight tile [k][n] row stride (dgrad): 320 B => tr reads conflict-free
 
-__device__ __forceinline__ uint2 pack4(f32x4 v) {
-  bf16x4 h;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) h[e] = (__bf16)v[e];
-  return __builtin_bit_cast(uint2, h);
-}
-__device__ __forceinline__ bf16x8 frag_direct(const u16* p) {  // 8 consecutive k
-  return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(p));
-}
-// 8 consecutive k (rows k0..k0+7 of a [k][col] image) for this lane's column, via two transposing reads.
-// `p` = address this lane supplies for the first 4-row block (see cdna_hip_programming.md T10).
-__device__ __forceinline__ bf16x8 frag_tr(const u16* p, int ld) {
-  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * ld));
-  typedef short s16x8 __attribute__((ext_vector_type(8)));
-  s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  return __builtin_bit_cast(bf16x8, r);
-}
 
 template <bool BKM, bool DG, bool UP, int XF>
 __global__ __launch_bounds__(NT, 4) void conv3_tile_bf16_kernel(vae_igemm_args p, int tiles_x, int tiles_y) {

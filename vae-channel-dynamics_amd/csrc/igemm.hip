@@ -28,6 +28,8 @@ bool wgrad3_tile_bf16_eligible(const vae_wgrad_args& a, bool vec);
 int64_t wgrad3_tile_bf16_units(const vae_conv_geom& g);
 int wgrad3_tile_bf16_columns(const vae_wgrad_args& a);
 int launch_wgrad3_tile_bf16(const vae_wgrad_args& a, hipStream_t st);
+int launch_rows_bf16(const vae_igemm_args& a, bool bkm, hipStream_t st);   // igemm_bf16.hip (vectorised shapes only)
+int launch_wgrad_bf16(const vae_wgrad_args& a, hipStream_t st);
 
 namespace {
 
@@ -626,6 +628,8 @@ extern "C" int vae_igemm_kernel_name(const vae_igemm_args* ap, char* buf, int32_
   if (rows_use_tile(a, vec, bkm))
     snprintf(buf, n, "conv3_tile%s_kernel<%s,%s,%s,%d>", a.prec == VAE_PREC_BF16 ? "_bf16" : "", tf[bkm],
              tf[a.g.mode == VAE_MODE_DGRAD], tf[a.g.mode == VAE_MODE_UP2X], a.xf);
+  else if (a.prec == VAE_PREC_BF16 && vec)
+    snprintf(buf, n, "igemm_rows_bf16_kernel<%s,%s,%d>", a.N <= 32 ? "128,32,4,1" : "128,128,4,2", tf[bkm], a.xf);
   else if (a.N <= 32)
     snprintf(buf, n, "igemm_rows_kernel<128,32,4,1,%s,%s,%d>", tf[bkm], tf[vec], a.xf);
   else
@@ -639,6 +643,8 @@ extern "C" int vae_wgrad_kernel_name(const vae_wgrad_args* ap, char* buf, int32_
   const char* tf[2] = {"false", "true"};
   if (wgrad_use_tile_bf16(a)) snprintf(buf, n, "wgrad3_tile_bf16_kernel<%s,%d>", tf[a.g.mode == VAE_MODE_UP2X], a.xf);
   else if (wgrad_use_tile(a)) snprintf(buf, n, "wgrad3_tile_kernel<%s,%d>", tf[a.g.mode == VAE_MODE_UP2X], a.xf);
+  else if (a.prec == VAE_PREC_BF16 && vec)
+    snprintf(buf, n, "wgrad_bf16_kernel<%s,%d>", a.M <= 32 ? "32,128,1,4" : (a.N <= 32 ? "128,32,4,1" : "128,128,4,2"), a.xf);
   else snprintf(buf, n, "wgrad_kernel<%s,%s,%d>", a.M <= 32 ? "32,128,1,4" : (a.N <= 32 ? "128,32,4,1" : "128,128,4,2"), tf[vec], a.xf);
   return VAE_OK;
 }
@@ -666,7 +672,13 @@ extern "C" int vae_igemm_rows(const vae_igemm_args* ap, void* stream) {
     VAE_LAUNCH_CHECK("conv3_tile");
     return VAE_OK;
   }
-  int rc = (a.N <= 32) ? launch_rows<128, 32, 4, 1>(a, bkm, vec, st) : launch_rows<128, 128, 4, 2>(a, bkm, vec, st);
+  int rc;
+  if (a.prec == VAE_PREC_BF16 && vec) {
+    VAE_CHECK(!bkm || a.xf == VAE_XF_NONE, "igemm_rows: xf unsupported with n-contiguous weights");
+    rc = launch_rows_bf16(a, bkm, st);
+  } else {
+    rc = (a.N <= 32) ? launch_rows<128, 32, 4, 1>(a, bkm, vec, st) : launch_rows<128, 128, 4, 2>(a, bkm, vec, st);
+  }
   if (rc) return rc;
   VAE_LAUNCH_CHECK("igemm_rows");
   return VAE_OK;
@@ -703,7 +715,8 @@ extern "C" int vae_wgrad(const vae_wgrad_args* ap, void* stream) {
   VAE_CHECK(a.xf == VAE_XF_NONE || xf_wgrad_ok(a.g, a.npix, a.nsplit, a.N),
             "wgrad: fused GroupNorm needs the split's scale/shift rows to fit LDS (see vae_wgrad_plan)");
   int rc;
-  if (a.M <= 32) rc = launch_wgrad<32, 128, 1, 4>(a, vec, st);
+  if (a.prec == VAE_PREC_BF16 && vec) rc = launch_wgrad_bf16(a, st);
+  else if (a.M <= 32) rc = launch_wgrad<32, 128, 1, 4>(a, vec, st);
   else if (a.N <= 32) rc = launch_wgrad<128, 32, 4, 1>(a, vec, st);
   else rc = launch_wgrad<128, 128, 4, 2>(a, vec, st);
   if (rc) return rc;

@@ -9,14 +9,10 @@
 // (their memory order); since the contraction runs over pixels, both MFMA operands need 8 consecutive PIXELS
 // per lane, which the transposing LDS load (ds_read_b64_tr_b16) delivers from the pixel-major images.
 // Wave (mt, kh) owns co rows mt*32.. and filter row kh: 3 taps x 2 ci sub-tiles = 6 accumulators.
-#include "common.h"
+#include "bf16_frag.h"
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef unsigned short u16;
 
 constexpr int TH = 2, TW = 32, UPX = TH * TW;   // 64 pixels per unit
 constexpr int HWD = TW + 2, HPX = (TH + 2) * HWD;  // 136 halo pixels
@@ -31,20 +27,6 @@ constexpr int AI = (AQ + NT - 1) / NT;          // 3
 constexpr int HQ = HPX * (BNT / 4);             // halo float4 slots (2176)
 constexpr int HI = (HQ + NT - 1) / NT;          // 3
 
-__device__ __forceinline__ uint2 pack4(f32x4 v) {
-  bf16x4 h;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) h[e] = (__bf16)v[e];
-  return __builtin_bit_cast(uint2, h);
-}
-__device__ __forceinline__ bf16x8 frag_tr(const u16* p, int ld) {
-  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * ld));
-  typedef short s16x8 __attribute__((ext_vector_type(8)));
-  s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  return __builtin_bit_cast(bf16x8, r);
-}
 
 template <bool UP, int XF>
 __global__ __launch_bounds__(NT) void wgrad3_tile_bf16_kernel(vae_wgrad_args p, int tiles_x, int tiles_y, int64_t nunits) {
