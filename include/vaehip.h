@@ -167,8 +167,8 @@ int vae_sample_kl(const float* moments, const float* eps, int32_t B, int32_t hw,
 int vae_mse_partial(const float* recon, const float* target, int64_t n, float* ws, int32_t nblk, void* stream);
 int vae_loss_final(const float* mse_ws, int32_t mse_nblk, int64_t mse_n, const float* kl_partial,
                    int32_t B, int32_t kl_nblk, float kl_weight, float* scalars, void* stream);
-/* d(total)/d(recon) = 2*(recon-target)/n                                             */
-int vae_mse_bwd(const float* recon, const float* target, int64_t n, float* drecon, void* stream);
+/* scale * d(total)/d(recon) = scale*2*(recon-target)/n  (scale = 1/gradient_accumulation_steps, train.py:286,299) */
+int vae_mse_bwd(const float* recon, const float* target, int64_t n, float scale, float* drecon, void* stream);
 /* d(total)/d(moments) from dz and the KL term                                        */
 int vae_sample_kl_bwd(const float* moments, const float* eps, const float* dz, int32_t B, int32_t hw,
                       int32_t L, float kl_weight, float* dmoments, void* stream);

@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(dll, name), f"{name} declared in vaehip.h but not exported"
     assert declared - {"vae_last_error", "vae_abi_version"} == set(SIGNATURES), "python binding table out of sync with the header"
-    assert lib.abi_version() == 1
+    assert lib.abi_version() == 2
     assert isinstance(dll.vae_last_error(), bytes)
 
 

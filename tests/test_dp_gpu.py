@@ -20,7 +20,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, accum=1):
     import sys
     for p in (os.path.join(ROOT, "vae-channel-dynamics_amd", "src"), os.path.join(ROOT, "oracle")):
         if p not in sys.path:
@@ -39,16 +39,21 @@ def _worker(rank, world, port, q):
             with torch.no_grad():
                 w.vae.arena.flat.mul_(1.5)
         tr = HipTrainer(w, lr=1e-3, lr_warmup_steps=0, max_train_steps=100, kl_weight=1e-4, max_grad_norm=1.0,
-                        scheduler_steps_per_update=1, bucket_mb=32.0)
+                        scheduler_steps_per_update=1, bucket_mb=32.0,
+                        gradient_accumulation_steps=accum)
         mon = ActivityMonitor(w, {"enabled": True, "track_interval": 1, "target_layers": [
             {"name": "vae.encoder.down_blocks.0.resnets.0.norm1", "capture_point": "output",
              "metrics": ["mean_abs_activation_per_channel"]}]})
         p0 = w.vae.arena.flat.clone()
         R, B = 32, 2
-        xs = [vo.synthetic_pixels(B, R, 42, 10 + r).to(dev) for r in range(world)]
-        es = [vo.synthetic_eps(B, R, 42, 10 + r).to(dev) for r in range(world)]
-        tr.train_step(xs[rank], es[rank])
-        launched = list(tr.reducer.launched)
+        nmb = world * accum  # micro-batches per update over all ranks
+        xs = [vo.synthetic_pixels(B, R, 42, 10 + r).to(dev) for r in range(nmb)]
+        es = [vo.synthetic_eps(B, R, 42, 10 + r).to(dev) for r in range(nmb)]
+        for j in range(accum):
+            assert tr.global_step == 0
+            tr.train_step(xs[rank * accum + j], es[rank * accum + j])
+        assert tr.global_step == 1 and tr.sync_gradients
+        launched = list(tr.reducer.launched) if accum == 1 else []
         mon.step(1)
         stat = mon.get_data_for_step(1)["vae.encoder.down_blocks.0.resnets.0.norm1.output"]["mean_abs_activation_per_channel"]
         after = w.vae.arena.flat.clone()
@@ -60,18 +65,18 @@ def _worker(rank, world, port, q):
         opt = FusedAdamW(w2.vae, lr=1e-3, max_grad_norm=1.0)
         gsum = torch.zeros_like(w2.vae.arena.grad)
         stats = []
-        for r in range(world):
+        for r in range(nmb):
             got = []
             h = w2.vae.engine.add_tracker(w2.vae.get_submodule("encoder.down_blocks.0.resnets.0.norm1"), "output", got.append)
             w2.vae.engine.forward_backward(xs[r], es[r], 1e-4)
             h.remove()
             stats.append(got[0])
             gsum += w2.vae.arena.grad
-        w2.vae.arena.grad.copy_(gsum / world)
+        w2.vae.arena.grad.copy_(gsum / nmb)
         opt.step()
         ref = w2.vae.arena.flat
         err = float((after - ref).abs().max() / ref.abs().max())
-        stat_ref = (torch.stack(stats).mean(0)).cpu().numpy()
+        stat_ref = (torch.stack(stats).mean(0)).cpu().numpy()  # monitor: mean over this step's forwards and over ranks
         stat_err = float(abs(stat - stat_ref).max() / abs(stat_ref).max())
         chk = after.double().sum().item()
         q.put((rank, err, stat_err, chk, launched, float((p0 - after).abs().max())))
@@ -79,12 +84,13 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_rank_step_equals_mean_gradient_step(cuda):
+@pytest.mark.parametrize("accum", [1, 2])
+def test_two_rank_step_equals_mean_gradient_step(cuda, accum):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, accum)) for r in range(world)]
     for p in procs:
         p.start()
     out = sorted(q.get(timeout=600) for _ in range(world))
@@ -92,10 +98,11 @@ def test_two_rank_step_equals_mean_gradient_step(cuda):
         p.join(timeout=120)
         assert p.exitcode == 0
     (r0, e0, s0, c0, l0, d0), (r1, e1, s1, c1, l1, d1) = out
-    assert e0 < 2e-6 and e1 < 2e-6, (e0, e1)       # == single-process step with the mean gradient
+    assert e0 < 4e-6 and e1 < 4e-6, (e0, e1)       # == single-process step with the mean gradient
     assert c0 == c1                                 # replicas bitwise identical after the step
     assert s0 < 1e-6 and s1 < 1e-6                  # tracker vector = mean over ranks
     assert d0 > 0                                   # parameters moved
-    # buckets were launched from the top of the arena downwards and cover it exactly once
-    assert l0 == l1 and l0[0][1] == 83_653_864 and l0[-1][0] == 0
-    assert all(l0[i][0] == l0[i + 1][1] for i in range(len(l0) - 1))
+    if accum == 1:
+        # buckets were launched from the top of the arena downwards and cover it exactly once
+        assert l0 == l1 and l0[0][1] == 83_653_864 and l0[-1][0] == 0
+        assert all(l0[i][0] == l0[i + 1][1] for i in range(len(l0) - 1))

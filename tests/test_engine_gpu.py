@@ -196,3 +196,69 @@ def test_bf16_compute_mode_tracks_fp32(pair):
         assert float(((stats["bf16"][n] - stats["no"][n]).abs() / stats["no"][n]).max()) < 2e-2
     with pytest.raises(NotImplementedError):
         eng.set_precision("fp16")
+
+
+def test_checkpointed_decoder_is_bitwise_identical(pair):
+    """training.gradient_checkpointing: decoder (BASELINE config 5) -- every resnet / attention / sampler of the decoder
+    keeps only its input and is re-run before its own backward.  Every kernel is deterministic, so losses and ALL
+    gradients are bit-identical, and trackers / hooks fire once per step, not once per pass."""
+    import vae_oracle as vo
+    o, w = pair
+    R, B, klw = 128, 2, 1e-3
+    x, eps = vo.synthetic_pixels(B, R, 42, 9).cuda(), vo.synthetic_eps(B, R, 42, 9).cuda()
+    eng = w.vae.engine
+    name = "decoder.up_blocks.1.resnets.0.norm1"
+    out = {}
+    for ck in (False, True):
+        eng.checkpoint_decoder = ck
+        fired, hooked = [], []
+        h1 = eng.add_tracker(w.vae.get_submodule(name), "output", lambda v: fired.append(v.clone()))
+        h2 = w.vae.decoder.conv_out.register_forward_hook(lambda m, i, o_: hooked.append(tuple(o_.shape)))
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        res = eng.forward_backward(x, eps, klw)
+        h1.remove(); h2.remove()
+        peak = torch.cuda.max_memory_allocated() - base
+        out[ck] = (res["scalars"].clone(), w.vae.arena.grad.clone(), fired, hooked, peak)
+        del res
+    eng.checkpoint_decoder = False
+    assert torch.equal(out[True][0], out[False][0])
+    assert torch.equal(out[True][1], out[False][1])
+    assert len(out[True][2]) == 1 and torch.equal(out[True][2][0], out[False][2][0])
+    assert out[True][3] == out[False][3] == [(B, 3, R, R)]
+    assert out[True][4] < out[False][4]  # the point of it: lower peak memory
+    print(f"peak memory {out[False][4] / 2**20:.0f} MiB -> {out[True][4] / 2**20:.0f} MiB with the decoder checkpointed")
+
+
+def test_gradient_accumulation_equals_full_batch_step(pair, cuda):
+    """training.gradient_accumulation_steps = 2 over two half batches == one step on the whole batch (GroupNorm is per
+    sample, both losses are batch means): same clipped AdamW update, one optimizer / scheduler step per two calls."""
+    import vae_oracle as vo
+    from models.sdxl_vae_wrapper import SDXLVAEWrapper
+    from vaehip.trainer import HipTrainer
+    o, w0 = pair
+    R, B = 32, 4
+    x, eps = vo.synthetic_pixels(B, R, 42, 3).cuda(), vo.synthetic_eps(B, R, 42, 3).cuda()
+    params, gnorm = {}, {}
+    for accum in (1, 2):
+        w = SDXLVAEWrapper("synthetic:1")
+        w.vae.load_state_dict(o.vae.state_dict())
+        w.to(cuda)
+        tr = HipTrainer(w, lr=1e-3, kl_weight=1e-3, lr_warmup_steps=1, max_train_steps=10, gradient_accumulation_steps=accum)
+        for it in range(2):  # two optimizer updates (the first has lr = 0, train.py:197-200)
+            if accum == 1:
+                tr.train_step(x, eps)
+                assert tr.sync_gradients
+            else:
+                tr.train_step(x[:2], eps[:2])
+                assert not tr.sync_gradients and tr.global_step == it
+                tr.train_step(x[2:], eps[2:])
+                assert tr.sync_gradients
+            assert tr.global_step == it + 1
+        params[accum] = w.vae.arena.flat.clone()
+        gnorm[accum] = float(w.vae.arena.grad.double().norm())
+    assert abs(gnorm[1] - gnorm[2]) / gnorm[1] < 1e-5
+    moved = (params[1] - w0.vae.arena.flat).abs().max()
+    assert float(moved) > 0
+    assert float((params[1] - params[2]).abs().max()) < 2e-2 * float(moved)  # Adam's sign-like first step amplifies rounding

@@ -328,10 +328,10 @@ extern "C" int vae_loss_final(const float* mse_ws, int32_t mse_nblk, int64_t mse
   VAE_LAUNCH_CHECK("loss_final");
   return VAE_OK;
 }
-extern "C" int vae_mse_bwd(const float* recon, const float* target, int64_t n, float* drecon, void* stream) {
+extern "C" int vae_mse_bwd(const float* recon, const float* target, int64_t n, float scale, float* drecon, void* stream) {
   VAE_CHECK(recon && target && drecon && n > 0, "mse_bwd: bad args");
   hipLaunchKernelGGL(mse_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, recon, target, n,
-                     (float)(2.0 / (double)n), drecon);
+                     (float)(2.0 * (double)scale / (double)n), drecon);
   VAE_LAUNCH_CHECK("mse_bwd");
   return VAE_OK;
 }

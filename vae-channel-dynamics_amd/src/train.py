@@ -165,9 +165,12 @@ def main():
     if mixed_precision not in ("no", "bf16"):
         raise NotImplementedError(f"training.mixed_precision={mixed_precision!r}: this path has 'no' (exact fp32 MFMA) and "
                                   "'bf16' (bf16 MFMA products, fp32 accumulate, fp32 master weights and statistics)")
-    if int(training_cfg.get("gradient_accumulation_steps", 1)) != 1:
-        raise NotImplementedError("gradient_accumulation_steps > 1 is not supported by the fused step "
-                                  "(all shipped configs use 1); use the autograd path of SDXLVAEWrapper for that")
+    grad_accum = int(training_cfg.get("gradient_accumulation_steps", 1))
+    # not a key of the reference's YAMLs (it never checkpoints): "decoder" re-runs the decoder forward before its backward
+    # instead of keeping its activations (BASELINE config 5)
+    grad_ckpt = training_cfg.get("gradient_checkpointing", False)
+    if grad_ckpt not in (False, None, "decoder", True):
+        raise NotImplementedError(f"training.gradient_checkpointing={grad_ckpt!r}: only 'decoder' exists")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -221,7 +224,7 @@ def main():
 
     # schedule arithmetic exactly as train.py:188-195 (max_train_steps ignores the world size)
     n_train = len(train_dataset) if hasattr(train_dataset, "__len__") else None
-    steps_per_epoch = math.ceil(n_train / bs / 1) if n_train else training_cfg.get("max_steps_per_epoch_iterable", 10000)
+    steps_per_epoch = math.ceil(n_train / bs / grad_accum) if n_train else training_cfg.get("max_steps_per_epoch_iterable", 10000)
     num_train_epochs = int(training_cfg.get("num_train_epochs", 1))
     max_train_steps = num_train_epochs * steps_per_epoch
     kl_weight = float(training_cfg.get("kl_weight", 1e-6))
@@ -232,7 +235,7 @@ def main():
         eps=training_cfg.get("adam_epsilon", 1e-08), weight_decay=training_cfg.get("adam_weight_decay", 1e-2),
         max_grad_norm=max_grad_norm, kl_weight=kl_weight, lr_warmup_steps=int(training_cfg.get("lr_warmup_steps", 100)),
         max_train_steps=max_train_steps, scheduler_steps_per_update=world,  # accelerate steps the scheduler `world` times
-        mixed_precision=mixed_precision)
+        mixed_precision=mixed_precision, gradient_accumulation_steps=grad_accum, checkpoint_decoder=bool(grad_ckpt))
 
     core_vae = vae_wrapper.vae
     dnt_cfg = config.get("dead_neuron_tracking", {})
@@ -273,6 +276,8 @@ def main():
             sc = res["scalars"]
             epoch_sums += sc.double()
             steps_in_epoch += 1
+            if not trainer.sync_gradients:  # micro-batch of an accumulated update (train.py:286,300)
+                continue
             global_step += 1
             activity_logs = {}
             if monitor and global_step % track_interval == 0:

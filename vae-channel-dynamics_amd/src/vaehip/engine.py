@@ -42,6 +42,11 @@ class Engine:
         self._low: Dict[int, int] = {}
         self._ident: Dict[tuple, Stats] = {}
         self.precision = ops.PREC_F32  # arithmetic of the 3x3 conv contractions (set_precision)
+        # activation checkpointing of the decoder (BASELINE config 5): every resnet / attention / sampler of the decoder
+        # keeps only its input; its forward is run again (recording) right before its own backward
+        self.checkpoint_decoder = False
+        self._ckpt = False    # inside a region whose segments are checkpointed
+        self._replay = False  # True while a checkpointed segment is re-run: trackers / hooks already fired
 
     # ------------------------------------------------------------------ plumbing
     @property
@@ -86,6 +91,8 @@ class Engine:
         return _TrackHandle(self._trackers, id(module), point, sink)
 
     def _tracked(self, m, point):
+        if self._replay:
+            return None
         d = self._trackers.get(id(m))
         return d.get(point) if d else None
 
@@ -110,7 +117,7 @@ class Engine:
 
     def _pre(self, m, make_in):
         sinks = self._tracked(m, "input")
-        if m._forward_pre_hooks or sinks:
+        if (m._forward_pre_hooks and not self._replay) or sinks:
             t = make_in()
             if sinks:
                 v = self._mean_abs(t)
@@ -125,7 +132,7 @@ class Engine:
             v = self._mean_abs(out)
             for s in sinks:
                 s(v)
-        if m._forward_hooks:
+        if m._forward_hooks and not self._replay:
             tin = self._present(m, make_in())
             for h in list(m._forward_hooks.values()):
                 h(m, (tin,), self._present(m, out))
@@ -145,7 +152,7 @@ class Engine:
             v = ops.gn_track(x, st)
             for s in sinks:
                 s(v)
-        if norm._forward_hooks:
+        if norm._forward_hooks and not self._replay:
             self._post(norm, lambda: x, ops.gn_apply(x, st, XF_AFFINE), tracked_already=True)
         return st
 
@@ -198,6 +205,26 @@ class Engine:
                 self._done(owner or m)
                 return dx
             tape.append(bwd)
+        return y
+
+    def _seg(self, run, x, tape):
+        """run(x, tape) -> y, checkpointed when the enclosing region asks for it: the forward records nothing and the
+        backward closure re-runs `run` on the kept input with a private tape (same kernels, bitwise the same values)."""
+        if tape is None or not self._ckpt:
+            return run(x, tape)
+        y = run(x, None)
+
+        def bwd(d):
+            local: list = []
+            self._replay = True
+            try:
+                run(x, local)
+            finally:
+                self._replay = False
+            while local:
+                d = local.pop()(d)
+            return d
+        tape.append(bwd)
         return y
 
     def _resnet(self, r, x, tape, notify=True):
@@ -262,9 +289,9 @@ class Engine:
         self._pre(mb, lambda: x)
         # registration order (attentions, resnets) differs from execution order, so the DP watermark
         # only moves once the whole mid block is final: after resnets[0]'s backward (last on the tape)
-        h = self._resnet(mb.resnets[0], x, tape, notify=mb)
-        h = self._attention(mb.attentions[0], h, tape, notify=False)
-        h = self._resnet(mb.resnets[1], h, tape, notify=False)
+        h = self._seg(lambda t, tp: self._resnet(mb.resnets[0], t, tp, notify=mb), x, tape)
+        h = self._seg(lambda t, tp: self._attention(mb.attentions[0], t, tp, notify=False), h, tape)
+        h = self._seg(lambda t, tp: self._resnet(mb.resnets[1], t, tp, notify=False), h, tape)
         self._post(mb, lambda: x, h)
         return h
 
@@ -278,10 +305,10 @@ class Engine:
         self._pre(blk, lambda: x)
         h = x
         for r in blk.resnets:
-            h = self._resnet(r, h, tape)
+            h = self._seg(lambda t, tp, r=r: self._resnet(r, t, tp), h, tape)
         extra = getattr(blk, "downsamplers", None) or getattr(blk, "upsamplers", None)
         if extra is not None:
-            h = self._sampler(extra[0], h, tape)
+            h = self._seg(lambda t, tp: self._sampler(extra[0], t, tp), h, tape)
         self._post(blk, lambda: x, h)
         return h
 
@@ -318,11 +345,15 @@ class Engine:
     def decoder_nhwc(self, z: torch.Tensor, tape) -> torch.Tensor:
         dec = self.vae.decoder
         self._pre(dec, lambda: z)
-        h = self._plain_conv(dec.conv_in, z, tape)
-        h = self._mid(dec.mid_block, h, tape)
-        for blk in dec.up_blocks:
-            h = self._updown_block(blk, h, tape)
-        h = self._norm_act_conv(dec, h, tape)
+        self._ckpt = bool(self.checkpoint_decoder) and tape is not None
+        try:
+            h = self._plain_conv(dec.conv_in, z, tape)
+            h = self._mid(dec.mid_block, h, tape)
+            for blk in dec.up_blocks:
+                h = self._updown_block(blk, h, tape)
+            h = self._norm_act_conv(dec, h, tape)
+        finally:
+            self._ckpt = False
         self._post(dec, lambda: z, h)
         return h
 
@@ -340,8 +371,10 @@ class Engine:
 
     # ------------------------------------------------------------------ fused train / eval step (fast path)
     def forward_backward(self, pixel_values: torch.Tensor, eps: Optional[torch.Tensor], kl_weight: float,
-                         sample_posterior: bool = True, generator: Optional[torch.Generator] = None):
-        """fwd + loss (train.py:289-291) + bwd; gradients are WRITTEN into arena.grad (no accumulation).
+                         sample_posterior: bool = True, generator: Optional[torch.Generator] = None,
+                         grad_scale: float = 1.0):
+        """fwd + loss (train.py:289-291) + bwd; gradients are WRITTEN into arena.grad (no accumulation), scaled by
+        `grad_scale` (= 1/gradient_accumulation_steps: accelerate divides the loss before backward, train.py:286,299).
         Returns dict(scalars[3]=mse,kl,total on device, reconstruction, moments, latents) as NHWC buffers."""
         self._require_gpu()
         pv = pixel_values.contiguous()
@@ -355,10 +388,10 @@ class Engine:
             z, klp = ops.sample_kl(mom, e)
             recon = self.decode_nhwc(z, td)
             scalars = ops.mse_kl_loss(recon, tgt, klp, kl_weight)
-            drec = ops.mse_bwd(recon, tgt)
+            drec = ops.mse_bwd(recon, tgt, grad_scale)
             self.arena.attach_grads()
             dz = self.run_tape(td, drec, self.arena.grad)
-            dmom = ops.sample_kl_bwd(mom, e, dz, kl_weight)
+            dmom = ops.sample_kl_bwd(mom, e, dz, kl_weight * grad_scale)
             self.run_tape(te, dmom, self.arena.grad)
         if self.reducer is not None:
             self.reducer.ready(0)

@@ -60,7 +60,7 @@ SIGNATURES = {
     "vae_sample_kl": [vp, vp, i32, i32, i32, vp, vp, vp],
     "vae_mse_partial": [vp, vp, i64, vp, i32, vp],
     "vae_loss_final": [vp, i32, i64, vp, i32, i32, f32, vp, vp],
-    "vae_mse_bwd": [vp, vp, i64, vp, vp],
+    "vae_mse_bwd": [vp, vp, i64, f32, vp, vp],
     "vae_sample_kl_bwd": [vp, vp, vp, i32, i32, i32, f32, vp, vp],
     "vae_nchw_to_nhwc": [vp, i32, i32, i32, i32, vp, vp],
     "vae_nhwc_to_nchw": [vp, i32, i32, i32, vp, vp],

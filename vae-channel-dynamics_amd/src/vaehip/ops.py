@@ -449,9 +449,9 @@ def mse_kl_loss(recon: torch.Tensor, target: torch.Tensor, kl_partial: torch.Ten
     return sc
 
 
-def mse_bwd(recon: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+def mse_bwd(recon: torch.Tensor, target: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
     d = torch.empty_like(recon)
-    lib.call("vae_mse_bwd", _p(recon), _p(target), recon.numel(), _p(d), _stream())
+    lib.call("vae_mse_bwd", _p(recon), _p(target), recon.numel(), float(scale), _p(d), _stream())
     return d
 
 
