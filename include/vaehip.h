@@ -85,6 +85,7 @@ typedef struct vae_igemm_args {
   int32_t xf;            /* VAE_XF_*                                              */
   float alpha;           /* C = alpha * acc (+bias+res); 1.0 for conv             */
   int32_t prec;          /* VAE_PREC_*: arithmetic of the products                */
+  const void* Wh;        /* optional (prec == BF16): bf16 image of W, same element layout (vae_pack_bf16); NULL = round W on the fly */
 } vae_igemm_args;
 int vae_igemm_rows(const vae_igemm_args* a, void* stream);
 /* 1 when xf != NONE can be fused for this geometry (the GroupNorm scale/shift rows a tile needs are staged in
@@ -179,6 +180,9 @@ int vae_nhwc_to_nchw(const float* src, int32_t B, int32_t C, int32_t HW, float* 
 /* dst[b][y][x][c] = sum of the 2x2 block of src[b][2y..][2x..][c] (dgrad of nearest-up2x) */
 int vae_sumpool2x2(const float* src, int32_t B, int32_t H, int32_t W, int32_t C, float* dst, void* stream);
 int vae_add(const float* a, const float* b, int64_t n, float* out, void* stream);
+/* dst[i] = bf16(src[i]) (round to nearest even): the bf16 weight image the bf16 kernels read through vae_igemm_args.Wh;
+ * run on the whole parameter arena once per step (replaces the per-step autocast weight casts of the reference) */
+int vae_pack_bf16(const float* src, int64_t n, void* dst, void* stream);
 
 /* ---- optimizer (K8,K9; train.py:184-187,301-302) ---- */
 /* sum of squares of g[0..n): stage 1 -> ws[nblk], stage 2 -> out[0]                   */

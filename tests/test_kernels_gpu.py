@@ -305,22 +305,46 @@ def bf16_mode():
     ops.PRECISION = ops.PREC_F32
 
 
+@pytest.fixture
+def packed_weights():
+    """hands every conv weight to the bf16 kernels as a pre-rounded bf16 image too (what the engine does per step)"""
+    from vaehip import ops
+    keep = []
+
+    def pack(wd):
+        buf = wd.permute(0, 2, 3, 1)  # the OHWI memory behind the logical OIHW view
+        assert buf.is_contiguous()
+        img = torch.empty(buf.numel(), device="cuda", dtype=torch.bfloat16)
+        ops.pack_bf16(buf, img)
+        keep.append(img)
+        ops.WEIGHTS16 = (buf.data_ptr(), buf.numel() * 4, img.data_ptr())
+        return wd
+    yield pack
+    ops.WEIGHTS16 = None
+
+
+# (5,128,128,128,128): 640 tiles on 512 persistent workgroups -- some run two tiles through the cross-tile pipeline
+@pytest.mark.parametrize("packed", [False, True])
 @pytest.mark.parametrize("kind,B,H,W,Ci,Co", [("c3", 2, 8, 32, 128, 128), ("c3", 1, 4, 64, 256, 512), ("c3", 2, 12, 32, 512, 256),
-                                              ("c3", 1, 4, 32, 96, 160), ("c3up", 2, 4, 16, 128, 256)])
-def test_bf16_conv_fwd_dgrad(cuda, bf16_mode, kind, B, H, W, Ci, Co):
+                                              ("c3", 1, 4, 32, 96, 160), ("c3up", 2, 4, 16, 128, 256),
+                                              ("c3", 2, 64, 64, 128, 128), ("c3", 5, 128, 128, 128, 128), ("c3", 3, 36, 96, 256, 128)])
+def test_bf16_conv_fwd_dgrad(cuda, bf16_mode, packed_weights, packed, kind, B, H, W, Ci, Co):
     from vaehip import ops
     gen = torch.Generator().manual_seed(99 + Ci + Co)
     x = torch.randn(B, Ci, H, W, generator=gen)
     w = torch.randn(Co, Ci, 3, 3, generator=gen) / math.sqrt(Ci * 9)
     b = torch.randn(Co, generator=gen)
+    _dev = _to_dev_ohwi(w)
+    if packed:
+        packed_weights(_dev)
     xr = _r16(x).requires_grad_(True)
     y_ref = _ref_conv(xr, _r16(w), b, kind)
     dy = torch.randn(y_ref.shape, generator=gen)
-    y = ops.conv_fwd(_nhwc(x), _to_dev_ohwi(w), b.cuda(), kind)
+    y = ops.conv_fwd(_nhwc(x), _dev, b.cuda(), kind)
     assert _rel(_nchw(y), y_ref.detach()) < 2e-5
     # dgrad: dY and W rounded to bf16
     (gx,) = torch.autograd.grad(_ref_conv(xr, _r16(w), None, kind), xr, _r16(dy))
-    dx = ops.conv_dgrad(_nhwc(dy), _to_dev_ohwi(w), kind, (H, W))
+    dx = ops.conv_dgrad(_nhwc(dy), _dev, kind, (H, W))
     assert _rel(_nchw(dx), gx) < 2e-5
     # and the bf16 result is close to the true fp32 conv at bf16 accuracy
     assert _rel(_nchw(y), _ref_conv(x, w, b, kind)) < 2e-2
@@ -335,10 +359,11 @@ def test_bf16_conv_fwd_dgrad(cuda, bf16_mode, kind, B, H, W, Ci, Co):
         assert _rel(gb.cpu(), dy.sum(dim=(0, 2, 3))) < 3e-5
 
 
-def test_bf16_conv_fused_gn_silu(cuda, bf16_mode):
+# (6,128,128,128,128): 768 tiles -- a persistent workgroup's second tile belongs to another image (other GroupNorm rows)
+@pytest.mark.parametrize("B,C,H,W,Co,packed", [(2, 128, 8, 32, 256, False), (2, 128, 8, 32, 256, True), (6, 128, 128, 128, 128, True)])
+def test_bf16_conv_fused_gn_silu(cuda, bf16_mode, packed_weights, B, C, H, W, Co, packed):
     from vaehip import ops
     gen = torch.Generator().manual_seed(5)
-    B, C, H, W, Co = 2, 128, 8, 32, 256
     x = torch.randn(B, C, H, W, generator=gen) * 1.3 + 0.2
     gamma, beta = 1 + 0.3 * torch.randn(C, generator=gen), 0.2 * torch.randn(C, generator=gen)
     w = torch.randn(Co, C, 3, 3, generator=gen) / math.sqrt(9 * C)
@@ -347,7 +372,10 @@ def test_bf16_conv_fused_gn_silu(cuda, bf16_mode):
     y_ref = F.conv2d(_r16(act), _r16(w), None, 1, 1) + res
     xd = _nhwc(x)
     st = ops.gn_stats(xd, gamma.cuda(), beta.cuda())
-    y = ops.conv_fwd(xd, _to_dev_ohwi(w), None, "c3", xf=ops.XF_AFFINE_SILU, stats=st, res=_nhwc(res))
+    wd = _to_dev_ohwi(w)
+    if packed:
+        packed_weights(wd)
+    y = ops.conv_fwd(xd, wd, None, "c3", xf=ops.XF_AFFINE_SILU, stats=st, res=_nhwc(res))
     # rounding of the fp32 activation to bf16 can differ by one bf16 ulp where the GPU/CPU fp32 values differ in the
     # last bit: allow a few 1e-4 of the output scale
     assert _rel(_nchw(y), y_ref) < 5e-4

@@ -36,6 +36,10 @@ def main():
         dy = torch.randn((B, H, H, Co), device="cuda", generator=g)
         wbuf = torch.randn((Co, 3, 3, Ci), device="cuda", generator=g) / math.sqrt(9 * Ci)
         w = wbuf.permute(0, 3, 1, 2)
+        if os.environ.get("MB_PACK") and hasattr(ops, "pack_bf16"):  # bf16 weight image, as the engine keeps it
+            img = torch.empty(wbuf.numel(), device="cuda", dtype=torch.bfloat16)
+            ops.pack_bf16(wbuf, img)
+            ops.WEIGHTS16 = (wbuf.data_ptr(), wbuf.numel() * 4, img.data_ptr())
         gw = torch.empty_like(wbuf).permute(0, 3, 1, 2)
         gb = torch.empty(Co, device="cuda")
         gamma = torch.ones(Ci, device="cuda")

@@ -1,240 +1,331 @@
 // bf16-compute variant of conv3_tile.hip (3x3 stride-1 convolution forward / forward over a virtual
 // nearest-2x upsample / dgrad) for `training.mixed_precision: bf16`:
-//   * activations, weights and outputs stay fp32 in HBM (fp32 master weights, fp32 statistics);
+//   * activations and outputs stay fp32 in HBM (fp32 statistics); weights are read from `Wh`, a bf16 image of the
+//     fp32 master copy with the same layout (vae_pack_bf16, once per step; without it the flat kernel serves the layer);
 //   * operands are rounded to bf16 while they are staged into LDS (after the fp32 GroupNorm+SiLU transform);
 //   * products run on v_mfma_f32_32x32x16_bf16 (16x the fp32-input MFMA rate), accumulation is fp32.
-// Same tiling as the fp32 kernel: 4x32-pixel output tile x 128 channels per 8-wave workgroup, the 9 taps share
-// one staged halo; the channel chunk is 64 (8 MFMAs per wave per barrier).  Forward reads both operands as
-// 16-byte k-contiguous fragments; dgrad keeps the weight tile in its memory order ([k = co][n = ci]) and reads
-// it with the transposing LDS load (ds_read_b64_tr_b16).
+// Tiling: 4x32-pixel output tile x 128 channels per workgroup; the halo (6x34 pixels x 32 channels) is shared by the
+// 9 taps.  At this MFMA rate LDS bandwidth and latency are the scarce resources (a 32x32x16 MFMA consumes 2 KB of
+// operands in 32 cycles; the LDS delivers 128 B/cycle to the CU's 4 SIMDs), so
+//   * a workgroup is FOUR waves with 64 pixel x 64 channel wave tiles (two image rows x two 32-channel blocks:
+//     4 fragments feed 4 MFMAs, 1 KB per MFMA), two workgroups per CU at 2 waves per SIMD (256-VGPR budget);
+//   * one barrier covers a whole kernel row: the weight stage holds the 3 taps of one kh (3 x 128 x 32), so a wave
+//     issues 24 MFMAs per barrier, and inside that block the fragments of MFMA group i+1 are read while group i runs;
+//   * the workgroups are PERSISTENT and run one software pipeline across tiles: the first halo and the first two
+//     weight stages of the next output tile are fetched during the last channel chunk of the current one, and the
+//     output stores of a tile drain under the next tile's MFMAs.  The GroupNorm scale/shift of the 4 channels a
+//     thread stages travel in registers with the halo (no LDS table, no extra barrier);
+//   * a step issues its MFMAs first, then waits for the weight stage of the next step (requested a step earlier) and
+//     requests the one after; the halo of the next channel chunk is requested two steps before it is needed.
+//     Vector-memory results return in order per wave, so the halo request goes BEHIND the weight request of its step
+//     (the next step's weight wait then does not wait for the slower HBM halo loads);
+// Forward reads both operands as 16-byte k-contiguous fragments; dgrad keeps the weight tile in its memory order
+// ([k = co][n = ci]) and reads it with the transposing LDS load (ds_read_b64_tr_b16).
 #include "bf16_frag.h"
+#include <algorithm>
 
 namespace {
 
-
-constexpr int BK = 64, TH = 4, TW = 32, HW_ = TW + 2, HP = (TH + 2) * HW_;  // 204 halo pixels
-constexpr int LDH = BK + 8;                 // halo row stride in bf16 (144 B: conflict-free ds_read_b128)
-constexpr int BN = 128, NT = 512;
+constexpr int BK = 32, TH = 4, TW = 32, HW_ = TW + 2, HP = (TH + 2) * HW_;  // 204 halo pixels
+constexpr int LDH = BK + 8;                 // halo row stride in bf16 (80 B: conflict-free ds_read_b128)
+constexpr int BN = 128, NT = 256;
 constexpr int SH = HP * LDH;                // halo stage (bf16 elements)
-constexpr int HQ = HP * (BK / 4);           // float4 slots of one halo (3264)
+constexpr int HQ = HP * (BK / 4);           // float4 slots of one halo (1632)
 constexpr int HI = (HQ + NT - 1) / NT;      // 7
 constexpr int LDBK = BK + 8;                // weight tile [n][k] row stride (forward)
 constexpr int LDBN = BN + 32;               // weight tile [k][n] row stride (dgrad): 320 B => tr reads conflict-free
+constexpr int SB1 = BN * LDBK;              // one tap of a weight stage; BN * LDBK == BK * LDBN
+static_assert(BN * LDBK == BK * LDBN, "forward and dgrad weight tiles have the same LDS size");
+constexpr int SB = 3 * SB1;                 // weight stage: the 3 taps of one kernel row
 
+struct TileId { int b, y0, x0, n0, lin; };
 
-template <bool BKM, bool DG, bool UP, int XF>
-__global__ __launch_bounds__(NT, 4) void conv3_tile_bf16_kernel(vae_igemm_args p, int tiles_x, int tiles_y) {
-  constexpr int LDB = BKM ? LDBN : LDBK;
-  constexpr int SB = BKM ? BK * LDBN : BN * LDBK;
-  constexpr int SSB = (XF != VAE_XF_NONE) ? 2 * SS_HALF * 2 : 0;  // fp32 table, counted in u16 units
-  __shared__ __attribute__((aligned(16))) u16 smem[SH + 2 * SB + SSB];
+template <bool DG, bool UP, int XF>
+__global__ __launch_bounds__(NT, 2) void conv3_tile_bf16_kernel(vae_igemm_args p, int tiles_x, int tiles_y, int ntiles) {
+  constexpr int LDB = DG ? LDBN : LDBK;
+  __shared__ __attribute__((aligned(16))) u16 smem[SH + 2 * SB];
   u16* sH = smem;
   u16* sBst = smem + SH;
-  float* sS = reinterpret_cast<float*>(smem + SH + 2 * SB);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int lr = lane & 31, lh = lane >> 5;
   const vae_conv_geom g = p.g;
   const int tilesN = (p.N + BN - 1) / BN;
-  int t = blockIdx.x;
-  const int tn = t % tilesN; t /= tilesN;
-  const int tx = t % tiles_x; t /= tiles_x;
-  const int ty = t % tiles_y;
-  const int b = t / tiles_y;
-  const int tile_lin = blockIdx.x / tilesN;
-  const int y0 = ty * TH, x0 = tx * TW, n0 = tn * BN;
-  const float* __restrict__ A = p.A;
-  const float* __restrict__ W = p.W;
+  // Both operand streams go through buffer descriptors: 32-bit per-lane byte offsets, and an out-of-range offset
+  // (OOB below) reads zeros -- padding pixels, channel tails and rows beyond N need no branch, no select on the
+  // loaded value (which would make the wave wait for the load at once) and no mask.
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, (unsigned)((size_t)g.B * g.Hs * g.Ws * g.Cs * 4u), 0x00020000);
+  const auto rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Wh), 0, (unsigned)((size_t)(DG ? p.K * p.sk : p.N * p.sn) * 2u), 0x00020000);
   const int Hb = UP ? 2 * g.Hs : g.Hs, Wb = UP ? 2 * g.Ws : g.Ws;
-
-  if (XF != VAE_XF_NONE) {
-    for (int c = tid; c < p.K; c += NT) {
-      sS[c] = p.scale[(int64_t)b * g.Cs + c];
-      sS[SS_HALF + c] = p.shift[(int64_t)b * g.Cs + c];
-    }
-  }
-
-  f32x16 acc[2];
-#pragma unroll
-  for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
-
   const int kchunks = (p.K + BK - 1) / BK;
-  const int steps = 9 * kchunks;
+  const int steps = 3 * kchunks;            // one step = one kernel row (3 taps) of one channel chunk
 
-  // ---- halo staging ----
+  // persistent schedule: consecutive logical ids (co-tile / x neighbours, which share halo rows) run on the same
+  // XCD (hardware places workgroup i on XCD i % 8) and therefore meet in the same L2
+  const int G = gridDim.x;
+  const int first = (G % 8 == 0) ? (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8 : blockIdx.x;
+  auto decode = [&](int t) {
+    TileId id;
+    id.lin = t / tilesN;
+    const int tn = t - id.lin * tilesN;
+    int r = id.lin;
+    const int tx = r % tiles_x; r /= tiles_x;
+    const int ty = r % tiles_y;
+    id.b = r / tiles_y;
+    id.y0 = ty * TH; id.x0 = tx * TW; id.n0 = tn * BN;
+    return id;
+  };
+
+  f32x16 acc[2][2];  // [row of the wave's row pair][32-channel block]
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  // ---- operand staging (register-staged) ----
+  constexpr int NW = 3 * BN * BK / 8 / NT;  // 6 uint4 of bf16 weights per thread and step
   f32x4 rh[HI];
-  int hmask = 0, hc0 = 0;
-  auto load_halo = [&](int c0) {
-    hc0 = c0;
+  uint4 rw[NW];                             // weight stage in flight
+  f32x4 rsc = {0.f, 0.f, 0.f, 0.f}, rsh = {0.f, 0.f, 0.f, 0.f};
+  int hmask = 0;
+  // Every staging routine starts from an opaque copy of the thread id: hipcc would otherwise hoist the ~25 per-slot
+  // addresses and masks out of the persistent loop and keep them in VGPRs (60+ registers, i.e. spills at the
+  // 256-register budget of 2 waves per SIMD); recomputing them costs a few VALU instructions per step.
+  auto opaque = [](int v) { asm volatile("" : "+v"(v)); return v; };
+  auto load_halo = [&](const TileId& id, int c0, bool valid) {
+    const unsigned Hv = valid ? (unsigned)Hb : 0u;  // an invalid request: every row out of range (no branch on `valid`)
+    const int ltid = opaque(tid), hk4 = ltid & (BK / 4 - 1);  // the thread's 4 channels: same for all its slots
     hmask = 0;
+    const int c = c0 + hk4 * 4;
+    if (XF != VAE_XF_NONE) {
+      const int cs = min(c, p.K - 4);
+      rsc = *reinterpret_cast<const f32x4*>(p.scale + (int64_t)id.b * g.Cs + cs);
+      rsh = *reinterpret_cast<const f32x4*>(p.shift + (int64_t)id.b * g.Cs + cs);
+    }
 #pragma unroll
     for (int i = 0; i < HI; ++i) {
-      const int q = tid + NT * i;
-      const int pp = q >> 4, k4 = q & 15;
+      const int q = ltid + NT * i;
+      const int pp = q / (BK / 4);
       const int ir = pp / HW_, jc = pp - ir * HW_;
-      const int hy = y0 - 1 + ir, hx = x0 - 1 + jc;
-      const int c = c0 + k4 * 4;
-      const bool ok = (q < HQ) && ((unsigned)hy < (unsigned)Hb) && ((unsigned)hx < (unsigned)Wb) && (c < p.K);
+      const int hy = id.y0 - 1 + ir, hx = id.x0 - 1 + jc;
+      const bool ok = (q < HQ) && ((unsigned)hy < Hv) && ((unsigned)hx < (unsigned)Wb) && (c < p.K);
       const int sy = UP ? (hy >> 1) : hy, sx = UP ? (hx >> 1) : hx;
-      rh[i] = load4g<true>(A + (((int64_t)b * g.Hs + sy) * g.Ws + sx) * g.Cs + c, ok, A, c, p.K);
+      const unsigned off = ok ? (unsigned)((((id.b * g.Hs + sy) * g.Ws + sx) * g.Cs + c) * 4) : OOB;
+      rh[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0));
       hmask |= (ok ? 1 : 0) << i;
     }
   };
   auto store_halo = [&]() {
+    const int ltid = opaque(tid), hk4 = ltid & (BK / 4 - 1);
 #pragma unroll
     for (int i = 0; i < HI; ++i) {
-      const int q = tid + NT * i;
+      const int q = ltid + NT * i;
       if (q < HQ) {
         f32x4 v = rh[i];
-        if (XF != VAE_XF_NONE) {
+        if (XF != VAE_XF_NONE) {  // padding must stay zero AFTER the transform
           const bool ok = (hmask >> i) & 1;
-          const int o = ok ? hc0 + (q & 15) * 4 : 0;
-          v = xform4_tab<XF>(v, sS + o, sS + SS_HALF + o, ok);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float u = v[e] * rsc[e] + rsh[e];
+            if (XF == VAE_XF_AFFINE_SILU) u = silu_f(u);
+            v[e] = ok ? u : 0.f;
+          }
         }
-        *reinterpret_cast<uint2*>(&sH[(q >> 4) * LDH + (q & 15) * 4]) = pack4(v);
+        *reinterpret_cast<uint2*>(&sH[(q / (BK / 4)) * LDH + hk4 * 4]) = pack4(v);
       }
     }
   };
-
-  // ---- weight staging: 128 x 64 tile, 4 float4 per thread ----
-  f32x4 rw[4];
-  auto load_w = [&](int s) {
-    const int cch = s / 9, tap = s - cch * 9;
-    const int c0 = cch * BK;
-    if (!BKM) {
-      const int k4 = tid & 15, r0 = tid >> 4;  // rows n = r0 + 32 i
-      const int c = c0 + k4 * 4;
+  // the 3 taps of kernel row kh for one channel chunk: 3 x (128 x 32) bf16 (forward [n][k], dgrad [k][n])
+  auto load_w = [&](uint4* dstreg, int n0, int c0, int kh, bool valid) {
+    const int ltid = opaque(tid);
+    const int Nv = valid ? p.N : 0;  // an invalid request: every column out of range (no branch on `valid`)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int n = n0 + r0 + 32 * i;
-        rw[i] = load4g<true>(W + (int64_t)n * p.sn + (int64_t)tap * p.st + c, n < p.N, W, c, p.K);
+    for (int i = 0; i < NW; ++i) {
+      const int tap = kh * 3 + (i >> 1);
+      const int rem = ltid + NT * (i & 1);
+      unsigned off;
+      if (!DG) {
+        const int n = n0 + (rem >> 2), c = c0 + (rem & 3) * 8;
+        off = (n < Nv && c < p.K) ? (unsigned)((n * (int)p.sn + tap * (int)p.st + c) * 2) : OOB;
+      } else {
+        const int k = c0 + (rem >> 4), n = n0 + (rem & 15) * 8;
+        off = (k < p.K && n < Nv) ? (unsigned)((k * (int)p.sk + tap * (int)p.st + n) * 2) : OOB;
       }
-    } else {
-      const int n4 = tid & 31, kq = tid >> 5;  // rows k = kq + 16 i
-      const int n = n0 + n4 * 4;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int k = c0 + kq + 16 * i;
-        rw[i] = load4g<true>(W + (int64_t)k * p.sk + (int64_t)tap * p.st + n, k < p.K, W, n, p.N);
-      }
+      dstreg[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsW, off, 0, 0));
     }
   };
-  auto store_w = [&](u16* sB) {
-    if (!BKM) {
-      const int k4 = tid & 15, r0 = tid >> 4;
+  auto store_w = [&](const uint4* srcreg, u16* sB) {
+    const int ltid = opaque(tid);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) *reinterpret_cast<uint2*>(&sB[(r0 + 32 * i) * LDB + k4 * 4]) = pack4(rw[i]);
-    } else {
-      const int n4 = tid & 31, kq = tid >> 5;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) *reinterpret_cast<uint2*>(&sB[(kq + 16 * i) * LDB + n4 * 4]) = pack4(rw[i]);
+    for (int i = 0; i < NW; ++i) {
+      const int rem = ltid + NT * (i & 1);
+      u16* dst = sB + (i >> 1) * SB1 + (DG ? (rem >> 4) * LDB + (rem & 15) * 8 : (rem >> 2) * LDB + (rem & 3) * 8);
+      *reinterpret_cast<uint4*>(dst) = srcreg[i];
     }
   };
 
   // lane's address pattern for the transposing read: group row q, column quad pp
   const int trq = (lane & 15) >> 2, trp = lane & 3, trh = (lane >> 4) & 1;
-  auto compute = [&](const u16* sA, const u16* sB) {
+  // one step: 6 MFMA groups (3 taps x 2 k-groups of 16 channels), each 2 pixel-row x 2 channel-block fragments and
+  // 4 MFMAs; the fragments of group i+1 are requested before the MFMAs of group i are issued
+  auto compute = [&](int kh, const u16* sB) {
+    const int dy = DG ? 2 - kh : kh;
+    const u16* aBase = sH + ((2 * wm + dy) * HW_ + lr) * LDH + lh * 8;
+    const u16* bBase = DG ? sB + (lh * 8 + trq) * LDB + wn * 64 + trh * 16 + trp * 4 : sB + (wn * 64 + lr) * LDB + lh * 8;
+    bf16x8 fa[2][2], fb[2][2];
+    auto fetch = [&](int grp, bf16x8* a, bf16x8* b) {
+      const int kw = grp >> 1, kg = grp & 1;
+      const int dx = DG ? 2 - kw : kw;
 #pragma unroll
-    for (int kg = 0; kg < BK / 16; ++kg) {
-      const bf16x8 a = frag_direct(sA + kg * 16 + lh * 8);
-      bf16x8 bq[2];
+      for (int mi = 0; mi < 2; ++mi) a[mi] = frag_direct(aBase + (mi * HW_ + dx) * LDH + kg * 16);
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
-        if (!BKM) {
-          bq[ni] = frag_direct(sB + (wn * 64 + ni * 32 + lr) * LDB + kg * 16 + lh * 8);
-        } else {
-          bq[ni] = frag_tr(sB + (kg * 16 + lh * 8 + trq) * LDB + wn * 64 + ni * 32 + trh * 16 + trp * 4, LDB);
-        }
+        if (!DG) b[ni] = frag_direct(bBase + kw * SB1 + ni * 32 * LDB + kg * 16);
+        else b[ni] = frag_tr(bBase + kw * SB1 + kg * 16 * LDB + ni * 32, LDB);
       }
+    };
+    fetch(0, fa[0], fb[0]);
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq[ni], acc[ni], 0, 0, 0);
+    for (int grp = 0; grp < 6; ++grp) {
+      if (grp + 1 < 6) fetch(grp + 1, fa[(grp + 1) & 1], fb[(grp + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);  // hipcc otherwise sinks each read to just before its MFMA and waits for it there
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[grp & 1][mi], fb[grp & 1][ni], acc[mi][ni], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
-  load_halo(0);
-  load_w(0);
-  __syncthreads();  // scale/shift table visible
+  int t = first;
+  if (t >= ntiles) return;  // uniform per workgroup
+  TileId cur = decode(t);
+  // Every step issues the same loads in the same order (a request that has no target -- nothing follows the last
+  // tile -- is made with every lane out of range): hipcc's waitcnt pass then knows exactly how many younger loads may
+  // stay in flight at each wait.  With conditional loads it assumes the fewest and waits for the halo at every step.
+  load_w(rw, cur.n0, 0, 0, true);
+  load_halo(cur, 0, true);
+  store_w(rw, sBst);
   store_halo();
-  store_w(sBst);
-  if (steps > 1) load_w(1);
+  load_w(rw, cur.n0, 0, 1, true);
   __syncthreads();
-  int cch = 0, tap = 0;
-  for (int s = 0; s < steps; ++s) {
-    const int kh = tap / 3, kw = tap - kh * 3;
-    const int dy = DG ? 2 - kh : kh, dx = DG ? 2 - kw : kw;
-    const u16* cA = sH + ((wm + dy) * HW_ + lr + dx) * LDH;
-    const u16* cB = sBst + (s & 1) * SB;
-    if (tap == 0 && cch + 1 < kchunks) load_halo((cch + 1) * BK);
-    if (s + 1 < steps) {
-      store_w(sBst + ((s + 1) & 1) * SB);
-      if (s + 2 < steps) load_w(s + 2);
-    }
-    compute(cA, cB);
-    __syncthreads();
-    if (++tap == 9) {
-      tap = 0;
-      if (++cch < kchunks) {
+  int par = 0;  // weight buffer holding the current step
+  while (true) {
+    const int tnext = t + G;
+    const bool has_next = tnext < ntiles;
+    const TileId nxt = decode(has_next ? tnext : t);
+    for (int cch = 0; cch < kchunks; ++cch) {
+      const bool last = cch + 1 == kchunks;
+      // where the chunk after this one lives: this tile's next chunk, or the first chunk of the next tile (if any)
+      const int c0n = last ? 0 : (cch + 1) * BK, n0n = last ? nxt.n0 : cur.n0;
+      const bool vn = !last || has_next;
+      // Each step issues its MFMAs first and only then waits for the weight stage of the next step (requested one
+      // step earlier), so the wait runs under the MFMAs; then it requests the stage after that.  The next chunk's
+      // (or next tile's first) halo is requested at the END of kernel row 0, behind that step's weight request.
+      compute(0, sBst + par * SB);
+      store_w(rw, sBst + (par ^ 1) * SB);
+      load_w(rw, cur.n0, cch * BK, 2, true);
+      load_halo(last ? nxt : cur, c0n, vn);
+      __syncthreads();
+      par ^= 1;
+      compute(1, sBst + par * SB);
+      store_w(rw, sBst + (par ^ 1) * SB);
+      load_w(rw, n0n, c0n, 0, vn);
+      __syncthreads();
+      par ^= 1;
+      compute(2, sBst + par * SB);
+      store_w(rw, sBst + (par ^ 1) * SB);
+      load_w(rw, n0n, c0n, 1, vn);
+      __syncthreads();
+      par ^= 1;
+      if (!last) {
         store_halo();
         __syncthreads();
       }
     }
-  }
 
-  // ---------------- epilogue (fp32) ----------------
-  const int oy = y0 + wm;
-  float tsum[2] = {0.f, 0.f};
+    // ---------------- epilogue (fp32); the stores drain under the next tile's main loop ----------------
+    float tsum[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const int col = n0 + wn * 64 + ni * 32 + lr;
-    const bool colok = col < p.N;
-    const float bv = (p.bias && colok) ? p.bias[col] : 0.f;
+    for (int mi = 0; mi < 2; ++mi) {
+      const int oy = cur.y0 + 2 * wm + mi;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int ox = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (colok && oy < g.Ho && ox < g.Wo) {
-        const int64_t o = (((int64_t)b * g.Ho + oy) * g.Wo + ox) * p.ldc + col;
-        float v = p.alpha * acc[ni][r] + bv;
-        if (p.res) v += p.res[o];
-        p.C[o] = v;
-        tsum[ni] += fabsf(v);
+      for (int ni = 0; ni < 2; ++ni) {
+        const int col = cur.n0 + wn * 64 + ni * 32 + lr;
+        const bool colok = col < p.N;
+        const float bv = (p.bias && colok) ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ox = cur.x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (colok && oy < g.Ho && ox < g.Wo) {
+            const int64_t o = (((int64_t)cur.b * g.Ho + oy) * g.Wo + ox) * p.ldc + col;
+            float v = p.alpha * acc[mi][ni][r] + bv;
+            if (p.res) v += p.res[o];
+            p.C[o] = v;
+            tsum[mi][ni] += fabsf(v);
+          }
+          acc[mi][ni][r] = 0.f;
+        }
       }
     }
-  }
-  if (p.track) {
-    float* red = reinterpret_cast<float*>(smem);  // [4][BN]
+    if (p.track) {  // uniform; the last loop barrier separated the halo reads from this reuse of its space
+      float* red = reinterpret_cast<float*>(smem);  // [4 rows][BN] fp32 = 2 KB of the 16 KB halo stage
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const float s2 = tsum[ni] + __shfl_xor(tsum[ni], 32, 64);
-      if (lh == 0) red[wm * BN + wn * 64 + ni * 32 + lr] = s2;
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const float s2 = tsum[mi][ni] + __shfl_xor(tsum[mi][ni], 32, 64);
+          if (lh == 0) red[(2 * wm + mi) * BN + wn * 64 + ni * 32 + lr] = s2;
+        }
+      __syncthreads();
+      if (tid < BN && cur.n0 + tid < p.N)
+        p.track[(int64_t)cur.lin * p.N + cur.n0 + tid] = (red[tid] + red[BN + tid]) + (red[2 * BN + tid] + red[3 * BN + tid]);
+      __syncthreads();
     }
+    if (!has_next) break;
+    store_halo();  // next tile's first channel chunk (in registers since the last chunk's first kernel row)
     __syncthreads();
-    if (tid < BN && n0 + tid < p.N)
-      p.track[(int64_t)tile_lin * p.N + n0 + tid] = (red[tid] + red[BN + tid]) + (red[2 * BN + tid] + red[3 * BN + tid]);
+    t = tnext;
+    cur = nxt;
   }
 }
 
-template <bool BKM, bool DG, bool UP>
-void launch_xf(const vae_igemm_args& a, dim3 grid, int tx, int ty, hipStream_t st) {
+template <bool DG, bool UP>
+void launch_xf(const vae_igemm_args& a, dim3 grid, int tx, int ty, int nt, hipStream_t st) {
   switch (a.xf) {
-    case VAE_XF_NONE: hipLaunchKernelGGL((conv3_tile_bf16_kernel<BKM, DG, UP, VAE_XF_NONE>), grid, dim3(NT), 0, st, a, tx, ty); break;
-    case VAE_XF_AFFINE: hipLaunchKernelGGL((conv3_tile_bf16_kernel<BKM, DG, UP, VAE_XF_AFFINE>), grid, dim3(NT), 0, st, a, tx, ty); break;
-    default: hipLaunchKernelGGL((conv3_tile_bf16_kernel<BKM, DG, UP, VAE_XF_AFFINE_SILU>), grid, dim3(NT), 0, st, a, tx, ty); break;
+    case VAE_XF_NONE: hipLaunchKernelGGL((conv3_tile_bf16_kernel<DG, UP, VAE_XF_NONE>), grid, dim3(NT), 0, st, a, tx, ty, nt); break;
+    case VAE_XF_AFFINE: hipLaunchKernelGGL((conv3_tile_bf16_kernel<DG, UP, VAE_XF_AFFINE>), grid, dim3(NT), 0, st, a, tx, ty, nt); break;
+    default: hipLaunchKernelGGL((conv3_tile_bf16_kernel<DG, UP, VAE_XF_AFFINE_SILU>), grid, dim3(NT), 0, st, a, tx, ty, nt); break;
   }
 }
 
 }  // namespace
 
+// the kernel reads the weights from their bf16 image in 16-byte (8-element) pieces: they must be aligned and never
+// straddle a row end
+bool conv3_tile_bf16_packed(const vae_igemm_args& a) {
+  const vae_conv_geom& g = a.g;
+  const bool fits32 = (size_t)g.B * g.Hs * g.Ws * g.Cs * 4u < 0xFFFFFFF0u &&  // buffer descriptors: 32-bit byte offsets
+                      (size_t)std::max((int64_t)a.K * a.sk, (int64_t)a.N * a.sn) * 2u < 0xFFFFFFF0u;
+  return a.Wh != nullptr && aligned16(a.Wh) && aligned16(a.A) && fits32 && a.K % 8 == 0 && a.N % 8 == 0 && a.st % 8 == 0 &&
+         (a.sn == 1 || a.sn % 8 == 0) && (a.sk == 1 || a.sk % 8 == 0);
+}
+
 int launch_conv3_tile_bf16(const vae_igemm_args& a, bool bkm, hipStream_t st) {
   const vae_conv_geom& g = a.g;
+  if (!conv3_tile_bf16_packed(a)) return VAE_EINVAL;
   const int tx = g.Wo / TW, ty = g.Ho / TH;
-  const int64_t nblk = (int64_t)((a.N + BN - 1) / BN) * tx * ty * g.B;
-  if (nblk > 0x7fffffffLL) return VAE_EINVAL;
-  dim3 grid((unsigned)nblk);
-  if (g.mode == VAE_MODE_DGRAD) launch_xf<true, true, false>(a, grid, tx, ty, st);
-  else if (g.mode == VAE_MODE_UP2X) launch_xf<false, false, true>(a, grid, tx, ty, st);
-  else launch_xf<false, false, false>(a, grid, tx, ty, st);
+  const int64_t nt = (int64_t)((a.N + BN - 1) / BN) * tx * ty * g.B;
+  if (nt > 0x7fffffffLL) return VAE_EINVAL;
+  dim3 grid((unsigned)std::min<int64_t>(nt, 512));  // persistent: two 4-wave workgroups per CU (LDS 76 KB each)
+  if (g.mode == VAE_MODE_DGRAD) launch_xf<true, false>(a, grid, tx, ty, (int)nt, st);
+  else if (g.mode == VAE_MODE_UP2X) launch_xf<false, true>(a, grid, tx, ty, (int)nt, st);
+  else launch_xf<false, false>(a, grid, tx, ty, (int)nt, st);
   return 0;
 }

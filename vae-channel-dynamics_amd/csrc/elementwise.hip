@@ -180,6 +180,28 @@ __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, c
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) o[i] = a[i] + b[i];
 }
 
+// fp32 -> bf16 image (round to nearest even), 8 elements per thread per trip: 32 B in, 16 B out
+__global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict__ src, int64_t n, unsigned short* __restrict__ dst) {
+  typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+  const int64_t n8 = n >> 3;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(src + i * 8);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(src + i * 8 + 4);
+    bf16x8_t h;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      h[e] = (__bf16)a[e];
+      h[4 + e] = (__bf16)b[e];
+    }
+    *reinterpret_cast<uint4*>(dst + i * 8) = __builtin_bit_cast(uint4, h);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
+    const int64_t i = (n8 << 3) + threadIdx.x;
+    const __bf16 h = (__bf16)src[i];
+    dst[i] = __builtin_bit_cast(unsigned short, h);
+  }
+}
+
 // ---------------- grad norm + AdamW ----------------
 __global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ ws) {
   __shared__ float red[4];
@@ -364,6 +386,14 @@ extern "C" int vae_add(const float* a, const float* b, int64_t n, float* out, vo
   VAE_CHECK(a && b && out && n > 0, "add: bad args");
   hipLaunchKernelGGL(add_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, n, out);
   VAE_LAUNCH_CHECK("add");
+  return VAE_OK;
+}
+
+extern "C" int vae_pack_bf16(const float* src, int64_t n, void* dst, void* stream) {
+  VAE_CHECK(src && dst && n > 0 && aligned16(src) && aligned16(dst), "pack_bf16: bad args");
+  hipLaunchKernelGGL(pack_bf16_kernel, dim3(ew_blocks((n + 7) / 8)), dim3(256), 0, (hipStream_t)stream, src, n,
+                     reinterpret_cast<unsigned short*>(dst));
+  VAE_LAUNCH_CHECK("pack_bf16");
   return VAE_OK;
 }
 

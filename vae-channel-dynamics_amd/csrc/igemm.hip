@@ -21,6 +21,7 @@
 bool conv3_tile_eligible(const vae_igemm_args& a, bool vec, bool bkm);
 int launch_conv3_tile(const vae_igemm_args& a, bool bkm, hipStream_t st);
 int launch_conv3_tile_bf16(const vae_igemm_args& a, bool bkm, hipStream_t st);
+bool conv3_tile_bf16_packed(const vae_igemm_args& a);
 bool wgrad3_tile_eligible(const vae_wgrad_args& a, bool vec);
 int64_t wgrad3_tile_units(const vae_conv_geom& g);
 int launch_wgrad3_tile(const vae_wgrad_args& a, hipStream_t st);
@@ -617,6 +618,10 @@ static bool rows_vec(const vae_igemm_args& a, bool bkm) {
 static bool rows_use_tile(const vae_igemm_args& a, bool vec, bool bkm) {
   return conv3_tile_eligible(a, vec, bkm) && !getenv("VAEHIP_FLAT_CONV");
 }
+// the bf16 halo-tile kernel reads the weights from their bf16 image; without one the bf16 flat kernel serves the layer
+static bool rows_use_tile_bf16(const vae_igemm_args& a, bool vec, bool bkm) {
+  return a.prec == VAE_PREC_BF16 && rows_use_tile(a, vec, bkm) && conv3_tile_bf16_packed(a);
+}
 
 // name of the kernel instantiation vae_igemm_rows / vae_wgrad dispatch to for these arguments
 // (profiling labels that match the rocprofv3 kernel names; no launch)
@@ -625,9 +630,10 @@ extern "C" int vae_igemm_kernel_name(const vae_igemm_args* ap, char* buf, int32_
   const vae_igemm_args& a = *ap;
   const bool bkm = rows_bkm(a), vec = rows_vec(a, bkm);
   const char* tf[2] = {"false", "true"};
-  if (rows_use_tile(a, vec, bkm))
-    snprintf(buf, n, "conv3_tile%s_kernel<%s,%s,%s,%d>", a.prec == VAE_PREC_BF16 ? "_bf16" : "", tf[bkm],
-             tf[a.g.mode == VAE_MODE_DGRAD], tf[a.g.mode == VAE_MODE_UP2X], a.xf);
+  if (rows_use_tile_bf16(a, vec, bkm))
+    snprintf(buf, n, "conv3_tile_bf16_kernel<%s,%s,%d>", tf[a.g.mode == VAE_MODE_DGRAD], tf[a.g.mode == VAE_MODE_UP2X], a.xf);
+  else if (a.prec != VAE_PREC_BF16 && rows_use_tile(a, vec, bkm))
+    snprintf(buf, n, "conv3_tile_kernel<%s,%s,%s,%d>", tf[bkm], tf[a.g.mode == VAE_MODE_DGRAD], tf[a.g.mode == VAE_MODE_UP2X], a.xf);
   else if (a.prec == VAE_PREC_BF16 && vec)
     snprintf(buf, n, "igemm_rows_bf16_kernel<%s,%s,%d>", a.N <= 32 ? "128,32,4,1" : "128,128,4,2", tf[bkm], a.xf);
   else if (a.N <= 32)
@@ -667,8 +673,13 @@ extern "C" int vae_igemm_rows(const vae_igemm_args* ap, void* stream) {
   const bool bkm = rows_bkm(a);
   const bool vec = rows_vec(a, bkm);
   hipStream_t st = (hipStream_t)stream;
-  if (rows_use_tile(a, vec, bkm)) {  // 3x3 stride-1: LDS halo tile shared by the 9 taps
-    if (int rc2 = (a.prec == VAE_PREC_BF16) ? launch_conv3_tile_bf16(a, bkm, st) : launch_conv3_tile(a, bkm, st)) return rc2;
+  if (rows_use_tile_bf16(a, vec, bkm)) {
+    if (int rc2 = launch_conv3_tile_bf16(a, bkm, st)) return rc2;
+    VAE_LAUNCH_CHECK("conv3_tile_bf16");
+    return VAE_OK;
+  }
+  if (a.prec != VAE_PREC_BF16 && rows_use_tile(a, vec, bkm)) {  // 3x3 stride-1: LDS halo tile shared by the 9 taps
+    if (int rc2 = launch_conv3_tile(a, bkm, st)) return rc2;
     VAE_LAUNCH_CHECK("conv3_tile");
     return VAE_OK;
   }

@@ -11,6 +11,7 @@ device-side reductions instead (add_tracker), without any tensor or host sync.
 """
 from __future__ import annotations
 
+import contextlib
 import weakref
 from typing import Callable, Dict, List, Optional
 
@@ -41,7 +42,8 @@ class Engine:
         self.reducer = None  # optional DP bucket reducer with .ready(low_offset)
         self._low: Dict[int, int] = {}
         self._ident: Dict[tuple, Stats] = {}
-        self.precision = ops.PREC_F32  # arithmetic of the 3x3 conv contractions (set_precision)
+        self.precision = ops.PREC_F32  # arithmetic of the conv contractions (set_precision)
+        self._flat16: Optional[torch.Tensor] = None  # bf16 image of the parameter arena (bf16 mode)
         # activation checkpointing of the decoder (BASELINE config 5): every resnet / attention / sampler of the decoder
         # keeps only its input; its forward is run again (recording) right before its own backward
         self.checkpoint_decoder = False
@@ -67,6 +69,27 @@ class Engine:
         else:
             raise NotImplementedError(f"mixed_precision={mode!r}: only 'no' and 'bf16' exist on this path "
                                       "(fp16 needs loss scaling, which the reference does not configure either)")
+
+    @contextlib.contextmanager
+    def _mode(self, repack: bool = True):
+        """arithmetic mode of the contraction kernels for one pass.  In bf16 mode the kernels read a bf16 image of the
+        parameter arena; a forward pass refreshes it first (parameters may have been stepped, nudged or loaded since),
+        a backward pass reuses the image its forward made."""
+        prev16 = ops.WEIGHTS16
+        with ops.precision(self.precision):
+            if self.precision == ops.PREC_BF16:
+                flat = self.arena.flat
+                img = self._flat16
+                if img is None or img.numel() != flat.numel() or img.device != flat.device:
+                    img = self._flat16 = torch.empty(flat.numel(), device=flat.device, dtype=torch.bfloat16)
+                    repack = True
+                if repack:
+                    ops.pack_bf16(flat, img)
+                ops.WEIGHTS16 = (flat.data_ptr(), flat.numel() * 4, img.data_ptr())
+            try:
+                yield
+            finally:
+                ops.WEIGHTS16 = prev16
 
     def _require_gpu(self):
         if self.arena.flat.device.type != "cuda":
@@ -378,7 +401,7 @@ class Engine:
         Returns dict(scalars[3]=mse,kl,total on device, reconstruction, moments, latents) as NHWC buffers."""
         self._require_gpu()
         pv = pixel_values.contiguous()
-        with ops.precision(self.precision):
+        with self._mode():
             x4 = ops.nchw_to_nhwc(pv, 4)
             tgt = ops.nchw_to_nhwc(pv, 3)
             te: list = []
@@ -404,7 +427,7 @@ class Engine:
         pv = pixel_values.contiguous()
         x4 = ops.nchw_to_nhwc(pv, 4)
         tgt = ops.nchw_to_nhwc(pv, 3)
-        with ops.precision(self.precision):
+        with self._mode():
             mom = self.encode_nhwc(x4, None)
             e = self._eps_nhwc(eps, mom, sample_posterior, generator)
             z, klp = ops.sample_kl(mom, e)
@@ -496,7 +519,7 @@ class _EncodeFn(torch.autograd.Function):
         need = record and any(p.requires_grad for p in params)
         tape = [] if need else None
         x4 = ops.nchw_to_nhwc(x.detach().to(dtype=torch.float32).contiguous(), 4)
-        with ops.precision(eng.precision):
+        with eng._mode():
             mom = eng.encode_nhwc(x4, tape)
         ctx.eng, ctx.tape, ctx.params = eng, tape, params
         return mom.permute(0, 3, 1, 2)
@@ -507,7 +530,7 @@ class _EncodeFn(torch.autograd.Function):
         if ctx.tape is None:
             raise RuntimeError("backward through a forward that recorded no tape")
         gbuf = torch.zeros_like(eng.arena.grad)
-        with ops.precision(eng.precision):
+        with eng._mode(repack=False):
             eng.run_tape(ctx.tape, dmom.permute(0, 2, 3, 1).contiguous(), gbuf)
         grads = [eng.arena.grad_view(p, gbuf) if p.requires_grad else None for p in ctx.params]
         return (None, None, None, *grads)
@@ -519,7 +542,7 @@ class _DecodeFn(torch.autograd.Function):
         need = record and (z.requires_grad or any(p.requires_grad for p in params))
         tape = [] if need else None
         zz = z.detach().to(dtype=torch.float32).permute(0, 2, 3, 1).contiguous()
-        with ops.precision(eng.precision):
+        with eng._mode():
             rec = eng.decode_nhwc(zz, tape)
         ctx.eng, ctx.tape, ctx.params = eng, tape, params
         return rec.permute(0, 3, 1, 2)
@@ -530,7 +553,7 @@ class _DecodeFn(torch.autograd.Function):
         if ctx.tape is None:
             raise RuntimeError("backward through a forward that recorded no tape")
         gbuf = torch.zeros_like(eng.arena.grad)
-        with ops.precision(eng.precision):
+        with eng._mode(repack=False):
             dz = eng.run_tape(ctx.tape, drec.permute(0, 2, 3, 1).contiguous(), gbuf)
         grads = [eng.arena.grad_view(p, gbuf) if p.requires_grad else None for p in ctx.params]
         return (None, None, dz.permute(0, 3, 1, 2), *grads)

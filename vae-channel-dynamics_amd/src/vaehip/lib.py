@@ -26,7 +26,7 @@ class IgemmArgs(C.Structure):
                 ("track", _fp), ("g", ConvGeom), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
                 ("ldc", C.c_int32), ("sn", C.c_int64), ("sk", C.c_int64), ("st", C.c_int64),
                 ("batch", C.c_int32), ("sAb", C.c_int64), ("sWb", C.c_int64), ("sCb", C.c_int64),
-                ("xf", C.c_int32), ("alpha", C.c_float), ("prec", C.c_int32)]
+                ("xf", C.c_int32), ("alpha", C.c_float), ("prec", C.c_int32), ("Wh", _fp)]
 
 
 class WgradArgs(C.Structure):
@@ -66,6 +66,7 @@ SIGNATURES = {
     "vae_nhwc_to_nchw": [vp, i32, i32, i32, vp, vp],
     "vae_sumpool2x2": [vp, i32, i32, i32, i32, vp, vp],
     "vae_add": [vp, vp, i64, vp, vp],
+    "vae_pack_bf16": [vp, i64, vp, vp],
     "vae_sqnorm": [vp, i64, vp, i32, vp, vp],
     "vae_adamw": [vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, f32, i32, vp],
     "vae_dead_scan": [vp, vp, i32, f32, vp, vp, vp],

@@ -17,6 +17,26 @@ PREC_F32, PREC_BF16 = 0, 1
 PRECISION = PREC_F32
 
 
+# bf16 image of a parameter arena (base address of the fp32 arena, its size in bytes, base address of the image):
+# weights that live inside the arena are handed to the bf16 kernels as `Wh` (set by the engine per forward)
+WEIGHTS16: Optional[Tuple[int, int, int]] = None
+
+
+def pack_bf16(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    """dst (bf16 storage, same numel) = round-to-nearest-even image of the fp32 tensor `src`."""
+    assert src.is_contiguous() and dst.is_contiguous() and dst.numel() == src.numel() and dst.element_size() == 2
+    lib.call("vae_pack_bf16", _p(src), src.numel(), _p(dst), _stream())
+    return dst
+
+
+def _wh(w: torch.Tensor):
+    if PRECISION != PREC_BF16 or WEIGHTS16 is None:
+        return None
+    base, nbytes, base16 = WEIGHTS16
+    off = w.data_ptr() - base
+    return C.c_void_p(base16 + off // 2) if 0 <= off < nbytes else None
+
+
 class precision:
     """context manager: arithmetic of the conv contractions inside the block (PREC_F32 | PREC_BF16)"""
 
@@ -174,7 +194,7 @@ def conv_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], kin
     a.M, a.N, a.K, a.ldc = B * g.Ho * g.Wo, Co, Ci, Co
     a.sn, a.sk, a.st = taps * Ci, 1, Ci
     a.batch, a.sAb, a.sWb, a.sCb = 1, 0, 0, 0
-    a.xf, a.alpha, a.prec = xf, 1.0, PRECISION
+    a.xf, a.alpha, a.prec, a.Wh = xf, 1.0, PRECISION, _wh(wv)
     if track is not None:
         assert track.numel() >= ((a.M + 127) // 128) * Co
     _launch_igemm(a)
@@ -209,7 +229,7 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, kind: str, in_hw: Tuple[int, i
     a.M, a.N, a.K, a.ldc = B * Hr * Wr, Ci, Co, Ci
     a.sn, a.sk, a.st = 1, taps * Ci, Ci
     a.batch, a.sAb, a.sWb, a.sCb = 1, 0, 0, 0
-    a.xf, a.alpha, a.prec = XF_NONE, 1.0, PRECISION
+    a.xf, a.alpha, a.prec, a.Wh = XF_NONE, 1.0, PRECISION, _wh(wv)
     _launch_igemm(a)
     if kind == "c3up":
         pooled = torch.empty((B, H, W, Ci), device=dy.device, dtype=torch.float32)
