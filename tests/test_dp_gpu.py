@@ -104,5 +104,5 @@ def test_two_rank_step_equals_mean_gradient_step(cuda, accum):
     assert d0 > 0                                   # parameters moved
     if accum == 1:
         # buckets were launched from the top of the arena downwards and cover it exactly once
-        assert l0 == l1 and l0[0][1] == 83_653_864 and l0[-1][0] == 0
+        assert l0 == l1 and l0[0][1] == 83_653_872 and l0[-1][0] == 0
         assert all(l0[i][0] == l0[i + 1][1] for i in range(len(l0) - 1))

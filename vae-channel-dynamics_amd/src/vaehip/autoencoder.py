@@ -209,7 +209,7 @@ class ParamArena:
 
     Conv weights keep the logical OIHW shape with OHWI (channels_last) memory so the kernels'
     implicit-GEMM weight tiles are contiguous along the contraction dimension.  Segment starts
-    are aligned to 16 B (float4 loads).  The fused AdamW / grad-norm / all-reduce run over the
+    are aligned to 32 B (float4 loads; 16-B loads from the bf16 image of the arena).  The fused AdamW / grad-norm / all-reduce run over the
     flat buffers; gaps stay zero."""
 
     def __init__(self, module: nn.Module, device: torch.device):
@@ -222,7 +222,7 @@ class ParamArena:
                 if p is None:
                     continue
                 owners.append((mod, pname, (mname + "." if mname else "") + pname, p, off))
-                off += (p.numel() + 3) // 4 * 4
+                off += (p.numel() + 7) // 8 * 8  # 32-B segments: the bf16 image of a segment (engine, bf16 mode) is 16-B aligned too
         self.total = off
         self.flat = torch.zeros(off, device=device, dtype=torch.float32)
         self.grad = torch.zeros(off, device=device, dtype=torch.float32)
