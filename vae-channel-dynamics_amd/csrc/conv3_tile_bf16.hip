@@ -89,7 +89,8 @@ __global__ __launch_bounds__(NT, 2) void conv3_tile_bf16_kernel(vae_igemm_args p
 
   // ---- operand staging (register-staged) ----
   constexpr int NW = 3 * BN * BK / 8 / NT;  // 6 uint4 of bf16 weights per thread and step
-  f32x4 rh[HI];
+  f32x4 rh[HI];                             // halo slots in flight (fp32, as loaded)
+  uint2 rhp[HI];                            // the same slots transformed and rounded to bf16, waiting for the barrier
   uint4 rw[NW];                             // weight stage in flight
   f32x4 rsc = {0.f, 0.f, 0.f, 0.f}, rsh = {0.f, 0.f, 0.f, 0.f};
   int hmask = 0;
@@ -120,24 +121,31 @@ __global__ __launch_bounds__(NT, 2) void conv3_tile_bf16_kernel(vae_igemm_args p
       hmask |= (ok ? 1 : 0) << i;
     }
   };
-  auto store_halo = [&]() {
+  // GroupNorm(+SiLU) and the rounding to bf16 happen in registers BEFORE the barrier that frees the halo stage (the
+  // VALU work runs under the MFMAs still in the pipe); behind the barrier only the ds_writes remain
+  auto xform_halo = [&]() {
+#pragma unroll
+    for (int i = 0; i < HI; ++i) {
+      f32x4 v = rh[i];
+      if (XF != VAE_XF_NONE) {  // padding must stay zero AFTER the transform
+        const bool ok = (hmask >> i) & 1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float u = v[e] * rsc[e] + rsh[e];
+          if (XF == VAE_XF_AFFINE_SILU) u = silu_f(u);
+          v[e] = ok ? u : 0.f;
+        }
+      }
+      rhp[i] = pack4(v);
+    }
+  };
+  auto write_halo = [&]() {
     const int ltid = opaque(tid), hk4 = ltid & (BK / 4 - 1);
 #pragma unroll
     for (int i = 0; i < HI; ++i) {
       const int q = ltid + NT * i;
-      if (q < HQ) {
-        f32x4 v = rh[i];
-        if (XF != VAE_XF_NONE) {  // padding must stay zero AFTER the transform
-          const bool ok = (hmask >> i) & 1;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float u = v[e] * rsc[e] + rsh[e];
-            if (XF == VAE_XF_AFFINE_SILU) u = silu_f(u);
-            v[e] = ok ? u : 0.f;
-          }
-        }
-        *reinterpret_cast<uint2*>(&sH[(q / (BK / 4)) * LDH + hk4 * 4]) = pack4(v);
-      }
+      if (q < HQ)
+        *reinterpret_cast<uint2*>(&sH[(q / (BK / 4)) * LDH + hk4 * 4]) = rhp[i];
     }
   };
   // the 3 taps of kernel row kh for one channel chunk: 3 x (128 x 32) bf16 (forward [n][k], dgrad [k][n])
@@ -212,7 +220,8 @@ __global__ __launch_bounds__(NT, 2) void conv3_tile_bf16_kernel(vae_igemm_args p
   load_w(rw, cur.n0, 0, 0, true);
   load_halo(cur, 0, true);
   store_w(rw, sBst);
-  store_halo();
+  xform_halo();
+  write_halo();
   load_w(rw, cur.n0, 0, 1, true);
   __syncthreads();
   int par = 0;  // weight buffer holding the current step
@@ -242,10 +251,11 @@ __global__ __launch_bounds__(NT, 2) void conv3_tile_bf16_kernel(vae_igemm_args p
       compute(2, sBst + par * SB);
       store_w(rw, sBst + (par ^ 1) * SB);
       load_w(rw, n0n, c0n, 1, vn);
+      xform_halo();  // the halo requested two steps ago (its loads are older than the weight request just made)
       __syncthreads();
       par ^= 1;
       if (!last) {
-        store_halo();
+        write_halo();
         __syncthreads();
       }
     }
@@ -289,7 +299,7 @@ __global__ __launch_bounds__(NT, 2) void conv3_tile_bf16_kernel(vae_igemm_args p
       __syncthreads();
     }
     if (!has_next) break;
-    store_halo();  // next tile's first channel chunk (in registers since the last chunk's first kernel row)
+    write_halo();  // next tile's first channel chunk (requested during the last chunk's first kernel row, transformed since)
     __syncthreads();
     t = tnext;
     cur = nxt;
