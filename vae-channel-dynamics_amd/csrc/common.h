@@ -117,6 +117,17 @@ __device__ __forceinline__ f32x4 load4g(const float* p, bool ok, const float* sa
   }
 }
 
+// Buffer-descriptor loads.  The descriptor covers [base, base + bytes) with a 32-bit per-lane byte offset; an offset
+// at or beyond `bytes` (use BUF_OOB) reads zeros.  Padding pixels, channel tails and rows beyond the matrix then need
+// neither a branch nor a select on the loaded value -- a select makes hipcc wait for the load right behind it, instead
+// of at the LDS write a pipeline step later.  Build the descriptor from wave-uniform values only.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned BUF_OOB = 0xFFFFFFF0u;
+constexpr size_t BUF_MAX = 0xFFFFFFF0u;  // bytes one descriptor can cover
+#define VAE_BUF_RSRC(ptr, bytes) \
+  __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(static_cast<const void*>(ptr)), 0, (unsigned)(bytes), 0x00020000)
+#define VAE_BUF_LOAD4(rsrc, off) __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128((rsrc), (off), 0, 0))
+
 // LDS-table variant: no bounds branches (table entries beyond the valid columns are zero-filled)
 template <int XF>
 __device__ __forceinline__ f32x4 xform4_tab(f32x4 v, const float* scale, const float* shift, bool ok) {

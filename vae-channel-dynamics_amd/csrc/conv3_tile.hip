@@ -10,6 +10,7 @@
 // ds_read_b128 fragment per k-group) and 64 channels.  Compared with the flat implicit GEMM
 // (igemm.hip) this removes 8/9 of the activation loads, address arithmetic and transforms.
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -43,8 +44,9 @@ __global__ __launch_bounds__(NT) void conv3_tile_kernel(vae_igemm_args p, int ti
   const int b = t / tiles_y;
   const int tile_lin = blockIdx.x / tilesN;
   const int y0 = ty * TH, x0 = tx * TW, n0 = tn * BN;
-  const float* __restrict__ A = p.A;
-  const float* __restrict__ W = p.W;
+  // operand streams through buffer descriptors (common.h): the activation descriptor covers this tile's image
+  const auto rsA = VAE_BUF_RSRC(p.A + (int64_t)b * g.Hs * g.Ws * g.Cs, (size_t)g.Hs * g.Ws * g.Cs * 4u);
+  const auto rsW = VAE_BUF_RSRC(p.W, (size_t)(BKM ? p.K * p.sk : p.N * p.sn) * 4u);
   const int Hb = UP ? 2 * g.Hs : g.Hs, Wb = UP ? 2 * g.Ws : g.Ws;  // bounds of the (virtual) source grid
 
   if (XF != VAE_XF_NONE) {
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(NT) void conv3_tile_kernel(vae_igemm_args p, int ti
       const int c = c0 + k4 * 4;
       const bool ok = (q < HQ) && ((unsigned)hy < (unsigned)Hb) && ((unsigned)hx < (unsigned)Wb) && (c < p.K);
       const int sy = UP ? (hy >> 1) : hy, sx = UP ? (hx >> 1) : hx;
-      rh[i] = load4g<true>(A + (((int64_t)b * g.Hs + sy) * g.Ws + sx) * g.Cs + c, ok, A, c, p.K);
+      rh[i] = VAE_BUF_LOAD4(rsA, ok ? (unsigned)(((sy * g.Ws + sx) * g.Cs + c) * 4) : BUF_OOB);
       hmask |= (ok ? 1 : 0) << i;
     }
   };
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(NT) void conv3_tile_kernel(vae_igemm_args p, int ti
 #pragma unroll
       for (int i = 0; i < BR; ++i) {
         const int n = n0 + r0w + RP * i;
-        rw[i] = load4g<true>(W + (int64_t)n * p.sn + (int64_t)tap * p.st + c, n < p.N, W, c, p.K);
+        rw[i] = VAE_BUF_LOAD4(rsW, (n < p.N && c < p.K) ? (unsigned)((n * (int)p.sn + tap * (int)p.st + c) * 4) : BUF_OOB);
       }
     } else {
       constexpr int NQ = BN / 4, KR = NT / NQ;
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(NT) void conv3_tile_kernel(vae_igemm_args p, int ti
       for (int i = 0; i < BR; ++i) {
         const int k = c0 + kq + KR * i;
         const int n = n0 + n4 * 4;
-        rw[i] = load4g<true>(W + (int64_t)k * p.sk + (int64_t)tap * p.st + n, k < p.K, W, n, p.N);
+        rw[i] = VAE_BUF_LOAD4(rsW, (k < p.K && n < p.N) ? (unsigned)((k * (int)p.sk + tap * (int)p.st + n) * 4) : BUF_OOB);
       }
     }
   };
@@ -236,6 +238,8 @@ bool conv3_tile_eligible(const vae_igemm_args& a, bool vec, bool bkm) {
   const vae_conv_geom& g = a.g;
   if (!vec || a.batch != 1 || g.taps != 9 || g.stride != 1 || g.pad_t != 1 || g.pad_l != 1) return false;
   if (a.N <= 32 || a.K % 4 != 0 || a.alpha != 1.0f) return false;
+  if ((size_t)g.Hs * g.Ws * g.Cs * 4u >= BUF_MAX) return false;  // one image per activation descriptor
+  if ((size_t)std::max((int64_t)a.K * a.sk, (int64_t)a.N * a.sn) * 4u >= BUF_MAX) return false;
   if (g.Wo % TW != 0 || g.Ho % TH != 0) return false;
   if (a.xf != VAE_XF_NONE && (a.K > SS_HALF || bkm)) return false;
   if (g.mode == VAE_MODE_FWD) return g.Ho == g.Hs && g.Wo == g.Ws && !bkm;

@@ -52,13 +52,9 @@ __global__ __launch_bounds__(NT, 2) void conv3_tile_bf16_kernel(vae_igemm_args p
   const int lr = lane & 31, lh = lane >> 5;
   const vae_conv_geom g = p.g;
   const int tilesN = (p.N + BN - 1) / BN;
-  // Both operand streams go through buffer descriptors: 32-bit per-lane byte offsets, and an out-of-range offset
-  // (OOB below) reads zeros -- padding pixels, channel tails and rows beyond N need no branch, no select on the
-  // loaded value (which would make the wave wait for the load at once) and no mask.
-  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  constexpr unsigned OOB = 0xFFFFFFF0u;
-  const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, (unsigned)((size_t)g.B * g.Hs * g.Ws * g.Cs * 4u), 0x00020000);
-  const auto rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Wh), 0, (unsigned)((size_t)(DG ? p.K * p.sk : p.N * p.sn) * 2u), 0x00020000);
+  // operand streams through buffer descriptors (common.h); the activation descriptor is made per tile (one image)
+  const size_t img_bytes = (size_t)g.Hs * g.Ws * g.Cs * 4u;
+  const auto rsW = VAE_BUF_RSRC(p.Wh, (size_t)(DG ? p.K * p.sk : p.N * p.sn) * 2u);
   const int Hb = UP ? 2 * g.Hs : g.Hs, Wb = UP ? 2 * g.Ws : g.Ws;
   const int kchunks = (p.K + BK - 1) / BK;
   const int steps = 3 * kchunks;            // one step = one kernel row (3 taps) of one channel chunk
@@ -103,6 +99,7 @@ __global__ __launch_bounds__(NT, 2) void conv3_tile_bf16_kernel(vae_igemm_args p
     const int ltid = opaque(tid), hk4 = ltid & (BK / 4 - 1);  // the thread's 4 channels: same for all its slots
     hmask = 0;
     const int c = c0 + hk4 * 4;
+    const auto rsA = VAE_BUF_RSRC(p.A + (int64_t)id.b * g.Hs * g.Ws * g.Cs, img_bytes);
     if (XF != VAE_XF_NONE) {
       const int cs = min(c, p.K - 4);
       rsc = *reinterpret_cast<const f32x4*>(p.scale + (int64_t)id.b * g.Cs + cs);
@@ -116,8 +113,7 @@ __global__ __launch_bounds__(NT, 2) void conv3_tile_bf16_kernel(vae_igemm_args p
       const int hy = id.y0 - 1 + ir, hx = id.x0 - 1 + jc;
       const bool ok = (q < HQ) && ((unsigned)hy < Hv) && ((unsigned)hx < (unsigned)Wb) && (c < p.K);
       const int sy = UP ? (hy >> 1) : hy, sx = UP ? (hx >> 1) : hx;
-      const unsigned off = ok ? (unsigned)((((id.b * g.Hs + sy) * g.Ws + sx) * g.Cs + c) * 4) : OOB;
-      rh[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0));
+      rh[i] = VAE_BUF_LOAD4(rsA, ok ? (unsigned)(((sy * g.Ws + sx) * g.Cs + c) * 4) : BUF_OOB);
       hmask |= (ok ? 1 : 0) << i;
     }
   };
@@ -159,10 +155,10 @@ __global__ __launch_bounds__(NT, 2) void conv3_tile_bf16_kernel(vae_igemm_args p
       unsigned off;
       if (!DG) {
         const int n = n0 + (rem >> 2), c = c0 + (rem & 3) * 8;
-        off = (n < Nv && c < p.K) ? (unsigned)((n * (int)p.sn + tap * (int)p.st + c) * 2) : OOB;
+        off = (n < Nv && c < p.K) ? (unsigned)((n * (int)p.sn + tap * (int)p.st + c) * 2) : BUF_OOB;
       } else {
         const int k = c0 + (rem >> 4), n = n0 + (rem & 15) * 8;
-        off = (k < p.K && n < Nv) ? (unsigned)((k * (int)p.sk + tap * (int)p.st + n) * 2) : OOB;
+        off = (k < p.K && n < Nv) ? (unsigned)((k * (int)p.sk + tap * (int)p.st + n) * 2) : BUF_OOB;
       }
       dstreg[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsW, off, 0, 0));
     }
@@ -321,8 +317,8 @@ void launch_xf(const vae_igemm_args& a, dim3 grid, int tx, int ty, int nt, hipSt
 // straddle a row end
 bool conv3_tile_bf16_packed(const vae_igemm_args& a) {
   const vae_conv_geom& g = a.g;
-  const bool fits32 = (size_t)g.B * g.Hs * g.Ws * g.Cs * 4u < 0xFFFFFFF0u &&  // buffer descriptors: 32-bit byte offsets
-                      (size_t)std::max((int64_t)a.K * a.sk, (int64_t)a.N * a.sn) * 2u < 0xFFFFFFF0u;
+  const bool fits32 = (size_t)g.Hs * g.Ws * g.Cs * 4u < BUF_MAX &&  // one image per activation descriptor
+                      (size_t)std::max((int64_t)a.K * a.sk, (int64_t)a.N * a.sn) * 2u < BUF_MAX;
   return a.Wh != nullptr && aligned16(a.Wh) && aligned16(a.A) && fits32 && a.K % 8 == 0 && a.N % 8 == 0 && a.st % 8 == 0 &&
          (a.sn == 1 || a.sn % 8 == 0) && (a.sk == 1 || a.sk % 8 == 0);
 }

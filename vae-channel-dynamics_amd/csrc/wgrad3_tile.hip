@@ -80,13 +80,16 @@ __global__ __launch_bounds__(NT) void wgrad3_tile_kernel(vae_wgrad_args p, int x
     const int rem = (int)(u - (int64_t)b * rows_per_img);
     const int ty = rem / xblocks, xb = rem - ty * xblocks;
     const int y = ty * TH;  // first output row of the unit
+    // buffer descriptors (common.h) over this unit's image of dY and of X: out-of-range offsets read zeros
+    const auto rsY = VAE_BUF_RSRC(p.dY + (int64_t)b * g.Ho * g.Wo * p.ldy, (size_t)g.Ho * g.Wo * p.ldy * 4u);
+    const auto rsX = VAE_BUF_RSRC(p.X + (int64_t)b * g.Hs * g.Ws * g.Cs, (size_t)g.Hs * g.Ws * g.Cs * 4u);
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       const int q = tid + NT * i;
       const int k = q >> 5;  // pixel of the unit: (row k / TW, col k % TW)
-      const int64_t pix = ((int64_t)b * g.Ho + y + k / TW) * g.Wo + xb * TW + (k % TW);
+      const int pix = (y + k / TW) * g.Wo + xb * TW + (k % TW);
       const int c = m0 + a4 * 4;
-      ra[i] = load4g<true>(p.dY + pix * p.ldy + c, q < AQ, p.dY, c, p.M);
+      ra[i] = VAE_BUF_LOAD4(rsY, (q < AQ && c < p.M) ? (unsigned)((pix * p.ldy + c) * 4) : BUF_OOB);
     }
     hb = b;
     hmask = 0;
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(NT) void wgrad3_tile_kernel(vae_wgrad_args p, int x
       const bool ok = (q < HQ) && ((unsigned)hy < (unsigned)Hb) && ((unsigned)hx < (unsigned)Wb);
       const int sy = UP ? (hy >> 1) : hy, sx = UP ? (hx >> 1) : hx;
       const int c = n0 + k4 * 4;
-      rh[i] = load4g<true>(p.X + (((int64_t)b * g.Hs + sy) * g.Ws + sx) * g.Cs + c, ok, p.X, c, p.N);
+      rh[i] = VAE_BUF_LOAD4(rsX, (ok && c < p.N) ? (unsigned)(((sy * g.Ws + sx) * g.Cs + c) * 4) : BUF_OOB);
       hmask |= (ok ? 1 : 0) << i;
     }
   };
@@ -199,6 +202,7 @@ bool wgrad3_tile_eligible(const vae_wgrad_args& a, bool vec) {
   if (g.mode == VAE_MODE_FWD && !(g.Ho == g.Hs && g.Wo == g.Ws)) return false;
   if (g.mode == VAE_MODE_UP2X && !(g.Ho == 2 * g.Hs && g.Wo == 2 * g.Ws)) return false;
   if (g.mode == VAE_MODE_DGRAD) return false;
+  if ((size_t)g.Ho * g.Wo * a.ldy * 4u >= BUF_MAX || (size_t)g.Hs * g.Ws * g.Cs * 4u >= BUF_MAX) return false;  // one image per descriptor
   return true;
 }
 

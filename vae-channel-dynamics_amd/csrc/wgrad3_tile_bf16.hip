@@ -79,13 +79,16 @@ __global__ __launch_bounds__(NT) void wgrad3_tile_bf16_kernel(vae_wgrad_args p, 
     const int rem = (int)(u - (int64_t)b * units_per_img);
     const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
     const int y0 = ty * TH, x0 = tx * TW;
+    // buffer descriptors (common.h) over this unit's image of dY and of X: out-of-range offsets read zeros
+    const auto rsY = VAE_BUF_RSRC(p.dY + (int64_t)b * g.Ho * g.Wo * p.ldy, (size_t)g.Ho * g.Wo * p.ldy * 4u);
+    const auto rsX = VAE_BUF_RSRC(p.X + (int64_t)b * g.Hs * g.Ws * g.Cs, (size_t)g.Hs * g.Ws * g.Cs * 4u);
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       const int q = tid + NT * i;
       const int px = q >> 5;  // 0..63 : (row px>>5, col px&31)
-      const int64_t pix = ((int64_t)b * g.Ho + y0 + (px >> 5)) * g.Wo + x0 + (px & 31);
+      const int pix = (y0 + (px >> 5)) * g.Wo + x0 + (px & 31);
       const int c = m0 + a4 * 4;
-      ra[i] = load4g<true>(p.dY + pix * p.ldy + c, q < AQ, p.dY, c, p.M);
+      ra[i] = VAE_BUF_LOAD4(rsY, (q < AQ && c < p.M) ? (unsigned)((pix * p.ldy + c) * 4) : BUF_OOB);
     }
     hb = b;
     hmask = 0;
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(NT) void wgrad3_tile_bf16_kernel(vae_wgrad_args p, 
       const bool ok = (q < HQ) && ((unsigned)hy < (unsigned)Hb) && ((unsigned)hx < (unsigned)Wb);
       const int sy = UP ? (hy >> 1) : hy, sx = UP ? (hx >> 1) : hx;
       const int c = n0 + k4 * 4;
-      rh[i] = load4g<true>(p.X + (((int64_t)b * g.Hs + sy) * g.Ws + sx) * g.Cs + c, ok, p.X, c, p.N);
+      rh[i] = VAE_BUF_LOAD4(rsX, (ok && c < p.N) ? (unsigned)(((sy * g.Ws + sx) * g.Cs + c) * 4) : BUF_OOB);
       hmask |= (ok ? 1 : 0) << i;
     }
   };
@@ -200,6 +203,7 @@ bool wgrad3_tile_bf16_eligible(const vae_wgrad_args& a, bool vec) {
   if (g.mode == VAE_MODE_FWD && !(g.Ho == g.Hs && g.Wo == g.Ws)) return false;
   if (g.mode == VAE_MODE_UP2X && !(g.Ho == 2 * g.Hs && g.Wo == 2 * g.Ws)) return false;
   if (g.mode == VAE_MODE_DGRAD) return false;
+  if ((size_t)g.Ho * g.Wo * a.ldy * 4u >= BUF_MAX || (size_t)g.Hs * g.Ws * g.Cs * 4u >= BUF_MAX) return false;  // one image per descriptor
   return true;
 }
 int64_t wgrad3_tile_bf16_units(const vae_conv_geom& g) { return (int64_t)g.B * (g.Ho / TH) * (g.Wo / TW); }
