@@ -35,6 +35,7 @@ int launch_wgrad_bf16(const vae_wgrad_args& a, hipStream_t st);
 namespace {
 
 constexpr int BK = 32;
+__device__ __forceinline__ int b_lo_of(int m0, int hw) { return m0 / hw; }
 
 // ---------------------------------------------------------------------------------------
 // rows kernel.  Pipeline: LDS is double buffered; the global loads of K-step s+2 are issued and
@@ -98,6 +99,15 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_rows_kernel(vae_igemm_args
     }
   };
 
+  // vectorised instantiations read both operands through buffer descriptors (common.h): out-of-range offsets read
+  // zeros, so no select sits on a loaded value.  The activation descriptor starts at the first image this tile's
+  // rows touch (the host checked that the images one tile can span fit 32-bit offsets).
+  const int b_base = s2c ? (m0 - cls * cls_rows) / (hh * wh) : b_lo_of(m0, hw);
+  const size_t img = (size_t)g.Hs * g.Ws * g.Cs;
+  const size_t abytes = (size_t)(g.B - b_base) * img * 4u, wbytes = (size_t)(BKM ? (int64_t)p.K * p.sk : (int64_t)p.N * p.sn) * 4u;
+  const auto rsA = VAE_BUF_RSRC(A + (int64_t)b_base * img, abytes < BUF_MAX ? abytes : BUF_MAX);
+  const auto rsW = VAE_BUF_RSRC(W, wbytes < BUF_MAX ? wbytes : BUF_MAX);
+
   // per-thread A rows
   const int k4 = lt & 7, r0 = lt >> 3;
   int rb[AR], ry[AR], rx[AR];
@@ -158,15 +168,19 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_rows_kernel(vae_igemm_args
     for (int i = 0; i < AR; ++i) {
       int sy = 0, sx = 0;
       const bool ok = src_pixel(g, ry[i], rx[i], kh, kw, sy, sx) && (rb[i] >= 0);
-      const float* src = A + (((int64_t)rb[i] * g.Hs + sy) * g.Ws + sx) * g.Cs + c;
-      ra[i] = load4g<VEC>(src, ok, A, c, p.K);
+      if (VEC) {
+        ra[i] = VAE_BUF_LOAD4(rsA, (ok && c < p.K) ? ((unsigned)(((rb[i] - b_base) * g.Hs + sy) * g.Ws + sx) * (unsigned)g.Cs + (unsigned)c) * 4u : BUF_OOB);
+      } else {
+        ra[i] = load4g<false>(A + (((int64_t)rb[i] * g.Hs + sy) * g.Ws + sx) * g.Cs + c, ok, A, c, p.K);
+      }
       a_b[i] = ok ? rb[i] : -1;
     }
     if (!BKM) {
 #pragma unroll
       for (int i = 0; i < BR; ++i) {
         const int n = n0 + r0 + RP * i;
-        rbw[i] = load4g<VEC>(W + (int64_t)n * p.sn + (int64_t)tap * p.st + c, n < p.N, W, c, p.K);
+        if (VEC) rbw[i] = VAE_BUF_LOAD4(rsW, (n < p.N && c < p.K) ? ((unsigned)n * (unsigned)p.sn + (unsigned)tap * (unsigned)p.st + (unsigned)c) * 4u : BUF_OOB);
+        else rbw[i] = load4g<false>(W + (int64_t)n * p.sn + (int64_t)tap * p.st + c, n < p.N, W, c, p.K);
       }
     } else {
       constexpr int NQ = BN / 4, KR = NL / NQ;
@@ -175,7 +189,8 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_rows_kernel(vae_igemm_args
       for (int i = 0; i < BR; ++i) {
         const int k = c0 + kq + KR * i;
         const int n = n0 + n4 * 4;
-        rbw[i] = load4g<VEC>(W + (int64_t)k * p.sk + (int64_t)tap * p.st + n, k < p.K, W, n, p.N);
+        if (VEC) rbw[i] = VAE_BUF_LOAD4(rsW, (k < p.K && n < p.N) ? ((unsigned)k * (unsigned)p.sk + (unsigned)tap * (unsigned)p.st + (unsigned)n) * 4u : BUF_OOB);
+        else rbw[i] = load4g<false>(W + (int64_t)k * p.sk + (int64_t)tap * p.st + n, k < p.K, W, n, p.N);
       }
     }
   };
@@ -361,6 +376,12 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(vae_wgrad_args p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
+  // buffer descriptors (vectorised instantiations): dY from this split's first pixel, X from its first image
+  const size_t img = (size_t)g.Hs * g.Ws * g.Cs;
+  const size_t ybytes = (size_t)(steps > 0 ? pend - pbeg : 0) * p.ldy * 4u, xbytes = (size_t)(g.B - b_lo) * img * 4u;
+  const auto rsY = VAE_BUF_RSRC(dY + (int64_t)pbeg * p.ldy, ybytes < BUF_MAX ? ybytes : BUF_MAX);
+  const auto rsX = VAE_BUF_RSRC(X + (int64_t)b_lo * img, xbytes < BUF_MAX ? xbytes : BUF_MAX);
+
   const int a4 = lt % AQ, akq = lt / AQ;
   const int b4 = lt % BQ, bkq = lt / BQ;
   f32x4 ra[AI], rx[BI];
@@ -373,7 +394,8 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(vae_wgrad_args p) {
     for (int i = 0; i < AI; ++i) {
       const int pix = pb + akq + AKR * i;
       const int c = m0 + a4 * 4;
-      ra[i] = load4g<VEC>(dY + (int64_t)pix * p.ldy + c, pix < pend, dY, c, p.M);
+      if (VEC) ra[i] = VAE_BUF_LOAD4(rsY, (pix < pend && c < p.M) ? ((unsigned)(pix - pbeg) * (unsigned)p.ldy + (unsigned)c) * 4u : BUF_OOB);
+      else ra[i] = load4g<false>(dY + (int64_t)pix * p.ldy + c, pix < pend, dY, c, p.M);
     }
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
@@ -383,7 +405,8 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(vae_wgrad_args p) {
       const int y = rem / g.Wo, x = rem - y * g.Wo;
       int sy = 0, sx = 0;
       const bool ok = src_pixel(g, y, x, kh, kw, sy, sx) && (pix < pend);
-      rx[i] = load4g<VEC>(X + (((int64_t)b * g.Hs + sy) * g.Ws + sx) * g.Cs + c, ok, X, c, p.N);
+      if (VEC) rx[i] = VAE_BUF_LOAD4(rsX, (ok && c < p.N) ? ((unsigned)(((b - b_lo) * g.Hs + sy) * g.Ws + sx) * (unsigned)g.Cs + (unsigned)c) * 4u : BUF_OOB);
+      else rx[i] = load4g<false>(X + (((int64_t)b * g.Hs + sy) * g.Ws + sx) * g.Cs + c, ok, X, c, p.N);
       xb[i] = ok ? b : -1;
     }
   };
@@ -683,6 +706,12 @@ extern "C" int vae_igemm_rows(const vae_igemm_args* ap, void* stream) {
     VAE_LAUNCH_CHECK("conv3_tile");
     return VAE_OK;
   }
+  if (vec) {  // flat vectorised kernels address one tile's images / the weights with 32-bit byte offsets
+    const int64_t rows_per_img = (a.g.mode == VAE_MODE_DGRAD_S2) ? (int64_t)a.g.Ho * a.g.Wo / 4 : (int64_t)a.g.Ho * a.g.Wo;
+    const int64_t span = std::min<int64_t>(a.g.B, rows_per_img % 128 == 0 ? 1 : 127 / rows_per_img + 2);
+    VAE_CHECK((size_t)span * a.g.Hs * a.g.Ws * a.g.Cs * 4u < BUF_MAX && (size_t)std::max(a.K * a.sk, a.N * a.sn) * 4u < BUF_MAX,
+              "igemm_rows: operand too large for 32-bit byte offsets");
+  }
   int rc;
   if (a.prec == VAE_PREC_BF16 && vec) {
     VAE_CHECK(!bkm || a.xf == VAE_XF_NONE, "igemm_rows: xf unsupported with n-contiguous weights");
@@ -725,6 +754,14 @@ extern "C" int vae_wgrad(const vae_wgrad_args* ap, void* stream) {
   }
   VAE_CHECK(a.xf == VAE_XF_NONE || xf_wgrad_ok(a.g, a.npix, a.nsplit, a.N),
             "wgrad: fused GroupNorm needs the split's scale/shift rows to fit LDS (see vae_wgrad_plan)");
+  if (vec) {  // 32-bit byte offsets inside one split's pixel range
+    const int64_t hw = (int64_t)a.g.Ho * a.g.Wo;
+    int64_t chunk = (a.npix + a.nsplit - 1) / a.nsplit;
+    chunk = (chunk + 31) / 32 * 32;
+    const int64_t span = std::min<int64_t>(a.g.B, chunk / hw + 2);
+    VAE_CHECK((size_t)chunk * a.ldy * 4u < BUF_MAX && (size_t)span * a.g.Hs * a.g.Ws * a.g.Cs * 4u < BUF_MAX,
+              "wgrad: operand too large for 32-bit byte offsets (raise nsplit)");
+  }
   int rc;
   if (a.prec == VAE_PREC_BF16 && vec) rc = launch_wgrad_bf16(a, st);
   else if (a.M <= 32) rc = launch_wgrad<32, 128, 1, 4>(a, vec, st);

@@ -65,6 +65,13 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_rows_bf16_kernel(vae_igemm
     }
   };
 
+  // operands through buffer descriptors (common.h; same conventions as the fp32 flat kernel)
+  const int b_base = s2c ? (m0 - cls * cls_rows) / (hh * wh) : m0 / hw;
+  const size_t img = (size_t)g.Hs * g.Ws * g.Cs;
+  const size_t abytes = (size_t)(g.B - b_base) * img * 4u, wbytes = (size_t)(BKM ? (int64_t)p.K * p.sk : (int64_t)p.N * p.sn) * 4u;
+  const auto rsA = VAE_BUF_RSRC(A + (int64_t)b_base * img, abytes < BUF_MAX ? abytes : BUF_MAX);
+  const auto rsW = VAE_BUF_RSRC(W, wbytes < BUF_MAX ? wbytes : BUF_MAX);
+
   const int k4 = tid & 15, r0 = tid >> 4;
   int rb[AR], ry[AR], rx[AR];
 #pragma unroll
@@ -121,14 +128,14 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_rows_bf16_kernel(vae_igemm
     for (int i = 0; i < AR; ++i) {
       int sy = 0, sx = 0;
       const bool ok = src_pixel(g, ry[i], rx[i], kh, kw, sy, sx) && (rb[i] >= 0);
-      ra[i] = load4g<true>(A + (((int64_t)rb[i] * g.Hs + sy) * g.Ws + sx) * g.Cs + c, ok, A, c, p.K);
+      ra[i] = VAE_BUF_LOAD4(rsA, (ok && c < p.K) ? ((unsigned)(((rb[i] - b_base) * g.Hs + sy) * g.Ws + sx) * (unsigned)g.Cs + (unsigned)c) * 4u : BUF_OOB);
       a_b[i] = ok ? rb[i] : -1;
     }
     if (!BKM) {
 #pragma unroll
       for (int i = 0; i < BR; ++i) {
         const int n = n0 + r0 + RP * i;
-        rw[i] = load4g<true>(W + (int64_t)n * p.sn + (int64_t)tap * p.st + c, n < p.N, W, c, p.K);
+        rw[i] = VAE_BUF_LOAD4(rsW, (n < p.N && c < p.K) ? ((unsigned)n * (unsigned)p.sn + (unsigned)tap * (unsigned)p.st + (unsigned)c) * 4u : BUF_OOB);
       }
     } else {
       constexpr int NQ = BN / 4, KR = NT / NQ;
@@ -137,7 +144,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_rows_bf16_kernel(vae_igemm
       for (int i = 0; i < BR; ++i) {
         const int k = c0 + kq + KR * i;
         const int n = n0 + n4 * 4;
-        rw[i] = load4g<true>(W + (int64_t)k * p.sk + (int64_t)tap * p.st + n, k < p.K, W, n, p.N);
+        rw[i] = VAE_BUF_LOAD4(rsW, (k < p.K && n < p.N) ? ((unsigned)k * (unsigned)p.sk + (unsigned)tap * (unsigned)p.st + (unsigned)n) * 4u : BUF_OOB);
       }
     }
   };
@@ -306,6 +313,11 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_bf16_kernel(vae_wgrad_args
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
+  const size_t img = (size_t)g.Hs * g.Ws * g.Cs;
+  const size_t ybytes = (size_t)(steps > 0 ? pend - pbeg : 0) * p.ldy * 4u, xbytes = (size_t)(g.B - b_lo) * img * 4u;
+  const auto rsY = VAE_BUF_RSRC(dY + (int64_t)pbeg * p.ldy, ybytes < BUF_MAX ? ybytes : BUF_MAX);
+  const auto rsX = VAE_BUF_RSRC(X + (int64_t)b_lo * img, xbytes < BUF_MAX ? xbytes : BUF_MAX);
+
   const int a4 = tid % AQ, akq = tid / AQ;
   const int b4 = tid % BQ, bkq = tid / BQ;
   f32x4 ra[AI], rx[BI];
@@ -318,7 +330,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_bf16_kernel(vae_wgrad_args
     for (int i = 0; i < AI; ++i) {
       const int pix = pb + akq + AKR * i;
       const int c = m0 + a4 * 4;
-      ra[i] = load4g<true>(dY + (int64_t)pix * p.ldy + c, pix < pend, dY, c, p.M);
+      ra[i] = VAE_BUF_LOAD4(rsY, (pix < pend && c < p.M) ? ((unsigned)(pix - pbeg) * (unsigned)p.ldy + (unsigned)c) * 4u : BUF_OOB);
     }
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
@@ -328,7 +340,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_bf16_kernel(vae_wgrad_args
       const int y = rem / g.Wo, x = rem - y * g.Wo;
       int sy = 0, sx = 0;
       const bool ok = src_pixel(g, y, x, kh, kw, sy, sx) && (pix < pend);
-      rx[i] = load4g<true>(X + (((int64_t)b * g.Hs + sy) * g.Ws + sx) * g.Cs + c, ok, X, c, p.N);
+      rx[i] = VAE_BUF_LOAD4(rsX, (ok && c < p.N) ? ((unsigned)(((b - b_lo) * g.Hs + sy) * g.Ws + sx) * (unsigned)g.Cs + (unsigned)c) * 4u : BUF_OOB);
       xb[i] = ok ? b : -1;
     }
   };
