@@ -72,13 +72,38 @@ __global__ __launch_bounds__(NT) void wgrad3_tile_bf16_kernel(vae_wgrad_args p, 
   f32x4 ra[AI], rh[HI];
   int hb = 0, hmask = 0;
   f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
-  const int a4 = tid & 31;  // dY column quad (NT % 32 == 0: the same for every slot of this thread)
+  // Staging routines start from an opaque copy of the thread id (hipcc would otherwise keep every slot's address and
+  // mask in VGPRs across the unit loop and spill), and EVERY step issues the same loads: a unit beyond the range is
+  // requested with all lanes out of range (zeros, no traffic), so the waitcnt pass knows exactly what is in flight.
+  // (the id is rebuilt from the wave number in an SGPR and the lane count of EXEC: no VGPR lives across the loop for it)
+  const int wave_s = __builtin_amdgcn_readfirstlane((int)threadIdx.x) >> 6;
+  auto fresh_tid = [&]() {
+    int l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(l));
+    return wave_s * 64 + l;
+  };
 
-  auto load_regs = [&](int64_t u) {
-    const int b = (int)(u / units_per_img);
-    const int rem = (int)(u - (int64_t)b * units_per_img);
-    const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
-    const int y0 = ty * TH, x0 = tx * TW;
+  // the unit to request next, decoded once and then advanced (image, tile row, tile column): no division per step
+  int nb_ = 0, nty_ = 0, ntx_ = 0, nleft_ = nu;
+  if (nu > 0) {
+    nb_ = (int)(ubeg / units_per_img);
+    const int rem = (int)(ubeg - (int64_t)nb_ * units_per_img);
+    nty_ = rem / tiles_x;
+    ntx_ = rem - nty_ * tiles_x;
+  }
+  auto load_regs = [&]() {
+    const int tid = fresh_tid();
+    const int a4 = tid & 31;  // dY column quad (NT % 32 == 0: the same for every slot of this thread)
+    const bool valid = nleft_ > 0;
+    const int AQv = valid ? AQ : 0;
+    const unsigned Hv = valid ? (unsigned)Hb : 0u;
+    const int b = nb_;
+    const int y0 = nty_ * TH, x0 = ntx_ * TW;
+    --nleft_;
+    if (++ntx_ == tiles_x) {
+      ntx_ = 0;
+      if (++nty_ == tiles_y) { nty_ = 0; ++nb_; }
+    }
     // buffer descriptors (common.h) over this unit's image of dY and of X: out-of-range offsets read zeros
     const auto rsY = VAE_BUF_RSRC(p.dY + (int64_t)b * g.Ho * g.Wo * p.ldy, (size_t)g.Ho * g.Wo * p.ldy * 4u);
     const auto rsX = VAE_BUF_RSRC(p.X + (int64_t)b * g.Hs * g.Ws * g.Cs, (size_t)g.Hs * g.Ws * g.Cs * 4u);
@@ -88,7 +113,7 @@ __global__ __launch_bounds__(NT) void wgrad3_tile_bf16_kernel(vae_wgrad_args p, 
       const int px = q >> 5;  // 0..63 : (row px>>5, col px&31)
       const int pix = (y0 + (px >> 5)) * g.Wo + x0 + (px & 31);
       const int c = m0 + a4 * 4;
-      ra[i] = VAE_BUF_LOAD4(rsY, (q < AQ && c < p.M) ? (unsigned)((pix * p.ldy + c) * 4) : BUF_OOB);
+      ra[i] = VAE_BUF_LOAD4(rsY, (q < AQv && c < p.M) ? (unsigned)((pix * p.ldy + c) * 4) : BUF_OOB);
     }
     hb = b;
     hmask = 0;
@@ -98,7 +123,7 @@ __global__ __launch_bounds__(NT) void wgrad3_tile_bf16_kernel(vae_wgrad_args p, 
       const int pp = q >> 4, k4 = q & 15;
       const int ir = pp / HWD, jc = pp - ir * HWD;
       const int hy = y0 - 1 + ir, hx = x0 - 1 + jc;
-      const bool ok = (q < HQ) && ((unsigned)hy < (unsigned)Hb) && ((unsigned)hx < (unsigned)Wb);
+      const bool ok = (q < HQ) && ((unsigned)hy < Hv) && ((unsigned)hx < (unsigned)Wb);
       const int sy = UP ? (hy >> 1) : hy, sx = UP ? (hx >> 1) : hx;
       const int c = n0 + k4 * 4;
       rh[i] = VAE_BUF_LOAD4(rsX, (ok && c < p.N) ? (unsigned)(((sy * g.Ws + sx) * g.Cs + c) * 4) : BUF_OOB);
@@ -106,6 +131,8 @@ __global__ __launch_bounds__(NT) void wgrad3_tile_bf16_kernel(vae_wgrad_args p, 
     }
   };
   auto store_lds = [&](u16* sA, u16* sH) {
+    const int tid = fresh_tid();
+    const int a4 = tid & 31;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       const int q = tid + NT * i;
@@ -128,37 +155,55 @@ __global__ __launch_bounds__(NT) void wgrad3_tile_bf16_kernel(vae_wgrad_args p, 
       }
     }
   };
-  auto compute = [&](const u16* sA, const u16* sH, int kg) {  // 16 consecutive pixels of tile row kg>>1
+  // One unit = 12 MFMA groups (4 k-groups of 16 pixels x 3 taps of this wave's kernel row), each 2 MFMAs (the two
+  // 32-channel ci blocks) on one dY fragment (shared by the 3 taps of a k-group) and two halo fragments.  The
+  // fragments of group i+1 are requested before the MFMAs of group i are issued (pinned with sched_barrier: hipcc
+  // otherwise sinks every read to just before its MFMA and waits for it there, 24 exposed LDS round trips per unit).
+  // this lane's element offsets into the dY image and the halo image (everything else is a compile-time constant)
+  const int aoff = (lh * 8 + trq) * LDA + mt * 32 + trh * 16 + trp * 4;
+  const int boff = (tg * HWD + lh * 8 + trq) * LDH + trh * 16 + trp * 4;
+  auto fetch_a = [&](const u16* sA, int kg) { return frag_tr(sA + aoff + kg * 16 * LDA, LDA); };
+  auto fetch_b = [&](const u16* sH, int grp, bf16x8* b) {
+    const int kg = grp / 3, t = grp - kg * 3;  // tap (kh = tg, kw = t): halo pixel (r + kh, c + kw)
     const int r = kg >> 1, c0 = (kg & 1) * 16;
-    const bf16x8 a = frag_tr(sA + (kg * 16 + lh * 8 + trq) * LDA + mt * 32 + trh * 16 + trp * 4, LDA);
+    const u16* hrow = sH + boff + (r * HWD + c0 + t) * LDH;
+    b[0] = frag_tr(hrow, LDH);
+    b[1] = frag_tr(hrow + 32, LDH);
+  };
+  bf16x8 fa[2], fb[2][2];
+  auto compute = [&](const u16* sA, const u16* sH, int g0, int g1) {  // MFMA groups [g0, g1) of the unit; g0 is prefetched
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {  // tap (kh = tg, kw = t): halo pixel (r + kh, c + kw)
-      const u16* hrow = sH + ((r + tg) * HWD + c0 + lh * 8 + trq + t) * LDH + trh * 16 + trp * 4;
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        const bf16x8 bq = frag_tr(hrow + ni * 32, LDH);
-        acc[t][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, acc[t][ni], 0, 0, 0);
+    for (int grp = g0; grp < g1; ++grp) {
+      const int kg = grp / 3, t = grp - kg * 3;
+      if (grp + 1 < 12) {
+        if (t == 2) fa[(kg + 1) & 1] = fetch_a(sA, kg + 1);
+        fetch_b(sH, grp + 1, fb[(grp + 1) & 1]);
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+        acc[t][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kg & 1], fb[grp & 1][ni], acc[t][ni], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
   if (nu > 0) {
-    load_regs(ubeg);
+    load_regs();
     __syncthreads();  // scale/shift table visible
     store_lds(smem, smem + SA);
-    if (nu > 1) load_regs(ubeg + 1);
+    load_regs();
     __syncthreads();
     for (int s = 0; s < nu; ++s) {
       const u16* cA = smem + (s & 1) * STAGE;
-      compute(cA, cA + SA, 0);
-      compute(cA, cA + SA, 1);
-      if (s + 1 < nu) {  // staged in the shadow of the MFMAs already issued
+      fa[0] = fetch_a(cA, 0);
+      fetch_b(cA + SA, 0, fb[0]);
+      compute(cA, cA + SA, 0, 6);
+      {  // staged in the shadow of the MFMAs already issued; unconditional (see load_regs)
         u16* nA = smem + ((s + 1) & 1) * STAGE;
         store_lds(nA, nA + SA);
-        if (s + 2 < nu) load_regs(ubeg + s + 2);
+        load_regs();
       }
-      compute(cA, cA + SA, 2);
-      compute(cA, cA + SA, 3);
+      compute(cA, cA + SA, 6, 12);
       __syncthreads();
     }
   }
