@@ -23,6 +23,7 @@
 // ([k = co][n = ci]) and reads it with the transposing LDS load (ds_read_b64_tr_b16).
 #include "bf16_frag.h"
 #include <algorithm>
+#include <type_traits>
 
 namespace {
 
@@ -117,23 +118,26 @@ __global__ __launch_bounds__(NT, 2) void conv3_tile_bf16_kernel(vae_igemm_args p
       hmask |= (ok ? 1 : 0) << i;
     }
   };
-  // GroupNorm(+SiLU) and the rounding to bf16 happen in registers BEFORE the barrier that frees the halo stage (the
-  // VALU work runs under the MFMAs still in the pipe); behind the barrier only the ds_writes remain
+  // GroupNorm(+SiLU) and the rounding to bf16 happen in registers BEFORE the barrier that frees the halo stage, one
+  // slot per MFMA group of the chunk's last step: the VALU instructions (two quarter-rate transcendentals per
+  // element) issue between that group's MFMAs and run while the matrix pipe works; behind the barrier only the
+  // ds_writes remain
+  auto xform_slot = [&](int i) {
+    f32x4 v = rh[i];
+    if (XF != VAE_XF_NONE) {  // padding must stay zero AFTER the transform
+      const bool ok = (hmask >> i) & 1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float u = v[e] * rsc[e] + rsh[e];
+        if (XF == VAE_XF_AFFINE_SILU) u = silu_f(u);
+        v[e] = ok ? u : 0.f;
+      }
+    }
+    rhp[i] = pack4(v);
+  };
   auto xform_halo = [&]() {
 #pragma unroll
-    for (int i = 0; i < HI; ++i) {
-      f32x4 v = rh[i];
-      if (XF != VAE_XF_NONE) {  // padding must stay zero AFTER the transform
-        const bool ok = (hmask >> i) & 1;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float u = v[e] * rsc[e] + rsh[e];
-          if (XF == VAE_XF_AFFINE_SILU) u = silu_f(u);
-          v[e] = ok ? u : 0.f;
-        }
-      }
-      rhp[i] = pack4(v);
-    }
+    for (int i = 0; i < HI; ++i) xform_slot(i);
   };
   auto write_halo = [&]() {
     const int ltid = opaque(tid), hk4 = ltid & (BK / 4 - 1);
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(NT, 2) void conv3_tile_bf16_kernel(vae_igemm_args p
   const int trq = (lane & 15) >> 2, trp = lane & 3, trh = (lane >> 4) & 1;
   // one step: 6 MFMA groups (3 taps x 2 k-groups of 16 channels), each 2 pixel-row x 2 channel-block fragments and
   // 4 MFMAs; the fragments of group i+1 are requested before the MFMAs of group i are issued
-  auto compute = [&](int kh, const u16* sB) {
+  auto compute = [&](auto with_xform, int kh, const u16* sB) {
     const int dy = DG ? 2 - kh : kh;
     const u16* aBase = sH + ((2 * wm + dy) * HW_ + lr) * LDH + lh * 8;
     const u16* bBase = DG ? sB + (lh * 8 + trq) * LDB + wn * 64 + trh * 16 + trp * 4 : sB + (wn * 64 + lr) * LDB + lh * 8;
@@ -203,9 +207,16 @@ __global__ __launch_bounds__(NT, 2) void conv3_tile_bf16_kernel(vae_igemm_args p
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[grp & 1][mi], fb[grp & 1][ni], acc[mi][ni], 0, 0, 0);
+      if (decltype(with_xform)::value) {  // the next chunk's halo, transformed under this group's MFMAs
+        static_assert(HI <= 12, "two halo slots per MFMA group at most");
+        if (grp < HI) xform_slot(grp);
+        if (grp + 6 < HI) xform_slot(grp + 6);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
+  constexpr std::integral_constant<bool, false> plain{};
+  constexpr std::integral_constant<bool, true> fused_xform{};
 
   int t = first;
   if (t >= ntiles) return;  // uniform per workgroup
@@ -233,21 +244,20 @@ __global__ __launch_bounds__(NT, 2) void conv3_tile_bf16_kernel(vae_igemm_args p
       // Each step issues its MFMAs first and only then waits for the weight stage of the next step (requested one
       // step earlier), so the wait runs under the MFMAs; then it requests the stage after that.  The next chunk's
       // (or next tile's first) halo is requested at the END of kernel row 0, behind that step's weight request.
-      compute(0, sBst + par * SB);
+      compute(plain, 0, sBst + par * SB);
       store_w(rw, sBst + (par ^ 1) * SB);
       load_w(rw, cur.n0, cch * BK, 2, true);
       load_halo(last ? nxt : cur, c0n, vn);
       __syncthreads();
       par ^= 1;
-      compute(1, sBst + par * SB);
+      compute(plain, 1, sBst + par * SB);
       store_w(rw, sBst + (par ^ 1) * SB);
       load_w(rw, n0n, c0n, 0, vn);
       __syncthreads();
       par ^= 1;
-      compute(2, sBst + par * SB);
+      compute(fused_xform, 2, sBst + par * SB);  // + transform of the halo requested two steps ago
       store_w(rw, sBst + (par ^ 1) * SB);
       load_w(rw, n0n, c0n, 1, vn);
-      xform_halo();  // the halo requested two steps ago (its loads are older than the weight request just made)
       __syncthreads();
       par ^= 1;
       if (!last) {

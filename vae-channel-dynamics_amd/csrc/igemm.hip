@@ -609,7 +609,7 @@ extern "C" int vae_wgrad_plan(const vae_wgrad_args* ap, int32_t* nsplit, int32_t
   if (wgrad_use_tile_bf16(a)) {
     const int64_t units = wgrad3_tile_bf16_units(a.g);
     const int64_t cols = wgrad3_tile_bf16_columns(a);
-    int64_t ns = std::max<int64_t>(1, std::min<int64_t>(512 / std::max<int64_t>(cols, 1), units / 4));
+    int64_t ns = std::max<int64_t>(1, std::min<int64_t>(256 / std::max<int64_t>(cols, 1), units / 4));
     *nsplit = (int32_t)std::max(ns, min_split(units, 64));
     *xf_fusable = 1;
     return VAE_OK;
@@ -617,7 +617,7 @@ extern "C" int vae_wgrad_plan(const vae_wgrad_args* ap, int32_t* nsplit, int32_t
   if (wgrad_use_tile(a)) {
     const int64_t units = wgrad3_tile_units(a.g);
     const int64_t wgs = (int64_t)((a.M + 127) / 128) * (a.N / 32);
-    int64_t ns = std::max<int64_t>(1, std::min<int64_t>(512 / std::max<int64_t>(wgs, 1), units / 8));  // 2 rounds of 256 CUs
+    int64_t ns = std::max<int64_t>(1, std::min<int64_t>(256 / std::max<int64_t>(wgs, 1), units / 8));  // one 12-wave workgroup per CU
     *nsplit = (int32_t)std::max(ns, min_split(units, 32));
     *xf_fusable = 1;
     return VAE_OK;
