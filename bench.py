@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tracking", action="store_true", help="A/B switch for the tracker-overhead measurement")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP-event timing")
+    ap.add_argument("--checkpoint-decoder", action="store_true",
+                    help="training.gradient_checkpointing: decoder (BASELINE configs[4], 1024x1024): decoder segments keep only their inputs")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -108,7 +110,7 @@ def main():
     w = SDXLVAEWrapper("synthetic:42", device=dev)
     trainer = HipTrainer(w, lr=1e-5, max_grad_norm=1.0, kl_weight=1e-6, lr_warmup_steps=100,
                          max_train_steps=10000, scheduler_steps_per_update=world,
-                         mixed_precision="bf16" if args.dtype == "bf16" else "no")
+                         mixed_precision="bf16" if args.dtype == "bf16" else "no", checkpoint_decoder=args.checkpoint_decoder)
     monitor = None if args.no_tracking else ActivityMonitor(w, TRACKING_CFG)
     classifier = None if args.no_tracking else RegionClassifier(w.vae, CLASSIFY_CFG)
 
@@ -179,6 +181,18 @@ def main():
                     "avg_launch_ms": round(dom[1]["ms"] / dom[1]["launches"], 4),
                     "all_contraction_kernels_tflops": round(allk, 2),
                     "contraction_ms_per_step": round(tot_ms / args.steps, 2)}
+        hbm = None  # step-level HBM rate (north_star: achieved HBM GB/s vs the 8 TB/s roofline), bytes from the committed PMC passes
+        try:
+            tfile = "r01_hbm_traffic.json" if args.dtype == "f32" else "r01_hbm_traffic_bf16.json"
+            with open(os.path.join(ROOT, "profiles", tfile)) as f:
+                tot = json.load(f).get("total_hbm_bytes_both_steps")
+            if tot and B == BATCH_PER_GPU and R == RES and not args.checkpoint_decoder:
+                per_step = tot / 2.0
+                gbps = per_step / (dt / args.steps) / 1e9
+                hbm = {"bytes_per_step": round(per_step), "achieved": round(gbps, 1), "peak": 8000.0, "unit": "GB/s",
+                       "frac": round(gbps / 8000.0, 4), "source": "rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/" + tfile}
+        except Exception:
+            hbm = None
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline()
@@ -194,7 +208,7 @@ def main():
                                    f"random-init weights (synthetic:42)",
                        "global_batch": world * B, "resolution": R, "parallelism": f"dp{world}"},
             "loss": {"mse": sc[0], "kl": sc[1], "total": sc[2]},
-            "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
+            "roofline": roof, "hbm_step": hbm, "cpu_baseline": cpu, "kernels": kernels,
         }
         print(json.dumps(line))
     if world > 1:

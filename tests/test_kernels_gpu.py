@@ -448,3 +448,17 @@ def test_bf16_flat_fused_gn(cuda, bf16_mode, C, H, W, silu):
     gw = torch.empty_like(_to_dev_ohwi(w).permute(0, 2, 3, 1).contiguous()).permute(0, 3, 1, 2)
     ops.conv_wgrad(_nhwc(dy), xd, "c3", gw, None, xf=xf, stats=st)
     assert _rel(gw.cpu(), wr.grad) < 5e-4
+
+
+@pytest.mark.parametrize("z,M,N,K", [(2, 64, 64, 512), (1, 256, 512, 256), (3, 100, 36, 40)])
+def test_bf16_batched_gemms(cuda, bf16_mode, z, M, N, K):
+    """attention GEMM forms in bf16 mode: operands rounded to bf16, exact products, fp32 accumulation"""
+    from vaehip import ops
+    gen = torch.Generator().manual_seed(z * 1000 + M)
+    A = torch.randn(z, M, K, generator=gen)
+    Bt = torch.randn(z, N, K, generator=gen)
+    Bn = torch.randn(z, K, N, generator=gen)
+    At = torch.randn(z, K, M, generator=gen)
+    assert _rel(ops.gemm_nt(A.cuda(), Bt.cuda(), 0.5), 0.5 * _r16(A) @ _r16(Bt).transpose(1, 2)) < 2e-5
+    assert _rel(ops.gemm_nn(A.cuda(), Bn.cuda()), _r16(A) @ _r16(Bn)) < 2e-5
+    assert _rel(ops.gemm_tn(At.cuda(), Bn.cuda(), 2.0), 2.0 * _r16(At).transpose(1, 2) @ _r16(Bn)) < 2e-5

@@ -369,7 +369,7 @@ def _gemm_rows(A, Bm, out, M, N, K, sn, sk, alpha, z, sAb, sWb, sCb):
     a.M, a.N, a.K, a.ldc = M, N, K, N
     a.sn, a.sk, a.st = sn, sk, 0
     a.batch, a.sAb, a.sWb, a.sCb = z, sAb, sWb, sCb
-    a.xf, a.alpha = XF_NONE, alpha
+    a.xf, a.alpha, a.prec = XF_NONE, alpha, PRECISION  # bf16 mode: scores / context / their gradients on the bf16 MFMA too
     _launch_igemm(a)
 
 
@@ -401,7 +401,7 @@ def gemm_tn(A: torch.Tensor, Bm: torch.Tensor, alpha: float = 1.0) -> torch.Tens
     a.g = ConvGeom(1, 1, K, N, 1, K, 1, 1, 0, 0, MODE_FWD)
     a.M, a.N, a.ldy, a.npix, a.nsplit = M, N, M, K, 1
     a.batch, a.sYb, a.sXb, a.sOb = z, K * M, K * N, M * N
-    a.xf, a.alpha = XF_NONE, alpha
+    a.xf, a.alpha, a.prec = XF_NONE, alpha, PRECISION  # bf16 mode: scores / context / their gradients on the bf16 MFMA too
     _launch_wgrad(a)
     return out
 
