@@ -86,6 +86,8 @@ typedef struct vae_igemm_args {
   float alpha;           /* C = alpha * acc (+bias+res); 1.0 for conv             */
   int32_t prec;          /* VAE_PREC_*: arithmetic of the products                */
   const void* Wh;        /* optional (prec == BF16): bf16 image of W, same element layout (vae_pack_bf16); NULL = round W on the fly */
+  const void* A16;       /* optional (prec == BF16, xf == NONE, vae_bf16_act_image_ok): bf16 image of the ALREADY TRANSFORMED
+                          * operand, same NHWC layout (vae_gn_apply_bf16); the kernel then reads it instead of A */
 } vae_igemm_args;
 int vae_igemm_rows(const vae_igemm_args* a, void* stream);
 /* 1 when xf != NONE can be fused for this geometry (the GroupNorm scale/shift rows a tile needs are staged in
@@ -110,6 +112,7 @@ typedef struct vae_wgrad_args {
   int32_t xf;
   float alpha;
   int32_t prec;          /* VAE_PREC_* */
+  const void* X16;       /* optional: as vae_igemm_args.A16, for X (xf must be NONE) */
 } vae_wgrad_args;
 int vae_wgrad(const vae_wgrad_args* a, void* stream);
 /* split-K plan for `a` (a->nsplit ignored): the nsplit to launch with, and whether a->xf can be fused
@@ -133,6 +136,13 @@ int vae_gn_stats_final(const float* ws, int32_t B, int32_t HW, int32_t C, int32_
 /* y = XF(x) materialised (only for layers with foreign hooks / full maps)        */
 int vae_gn_apply(const float* x, const float* scale, const float* shift, int32_t B, int32_t HW,
                  int32_t C, int32_t xf, float* y, void* stream);
+/* y16 = bf16(XF(x)): the activation image of a GroupNorm(+SiLU)'d conv input for bf16 mode (C % 8 == 0); the layer's
+ * forward and wgrad then read 2 B per element and transform nothing (vae_igemm_args.A16 / vae_wgrad_args.X16)      */
+int vae_gn_apply_bf16(const float* x, const float* scale, const float* shift, int32_t B, int32_t HW,
+                      int32_t C, int32_t xf, void* y16, void* stream);
+/* 1 when BOTH the forward (vae_igemm_rows) and the weight gradient (vae_wgrad) of the 3x3 stride-1 layer with this
+ * forward geometry, Cout and Cin accept a bf16 activation image in bf16 mode (the halo-tile kernels serve them)   */
+int vae_bf16_act_image_ok(const vae_conv_geom* fwd_geom, int32_t Cout, int32_t Cin);
 /* tracker (monitor.py:66): partial sums of |x*scale+shift| per (b,chunk,c);
  * ws [B][nchunk][C]; then vae_track_final                                         */
 int vae_gn_track_partial(const float* x, const float* scale, const float* shift, int32_t B, int32_t HW,

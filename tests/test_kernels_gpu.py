@@ -462,3 +462,40 @@ def test_bf16_batched_gemms(cuda, bf16_mode, z, M, N, K):
     assert _rel(ops.gemm_nt(A.cuda(), Bt.cuda(), 0.5), 0.5 * _r16(A) @ _r16(Bt).transpose(1, 2)) < 2e-5
     assert _rel(ops.gemm_nn(A.cuda(), Bn.cuda()), _r16(A) @ _r16(Bn)) < 2e-5
     assert _rel(ops.gemm_tn(At.cuda(), Bn.cuda(), 2.0), 2.0 * _r16(At).transpose(1, 2) @ _r16(Bn)) < 2e-5
+
+
+@pytest.mark.parametrize("B,C,H,W,Co", [(2, 128, 8, 32, 256), (6, 128, 128, 128, 128), (1, 256, 4, 64, 128)])
+def test_bf16_activation_image(cuda, bf16_mode, packed_weights, B, C, H, W, Co):
+    """bf16 mode, large 3x3 layers: silu(gn(x)) is rounded to bf16 ONCE (vae_gn_apply_bf16) and the forward and the
+    weight gradient read that image (A16 / X16) instead of transforming the fp32 input while staging it."""
+    from vaehip import ops
+    gen = torch.Generator().manual_seed(17 + C + H)
+    x = torch.randn(B, C, H, W, generator=gen) * 1.3 + 0.2
+    gamma, beta = 1 + 0.3 * torch.randn(C, generator=gen), 0.2 * torch.randn(C, generator=gen)
+    w = torch.randn(Co, C, 3, 3, generator=gen) / math.sqrt(9 * C)
+    act = F.silu(F.group_norm(x, 32, gamma, beta, 1e-6))
+    xd, wd = _nhwc(x), packed_weights(_to_dev_ohwi(w))
+    assert ops.act_image_ok("c3", xd.shape, Co, C)
+    assert not ops.act_image_ok("c3", (B, 5, 7, C), Co, C) and not ops.act_image_ok("c1", xd.shape, Co, C)
+    st = ops.gn_stats(xd, gamma.cuda(), beta.cuda())
+    a16 = ops.gn_apply_bf16(xd, st, ops.XF_AFFINE_SILU)
+    # the image is the bf16 rounding of the fp32 transform (one bf16 ulp where GPU / CPU fp32 differ in the last bit)
+    assert _rel(a16.float().permute(0, 3, 1, 2), _r16(act)) < 8e-3
+    img = a16.float().permute(0, 3, 1, 2).cpu()           # what the kernels must contract, exactly
+    prof = ops.PROFILER = ops.LaunchProfiler()
+    try:
+        y = ops.conv_fwd(xd, wd, None, "c3", xf=ops.XF_AFFINE_SILU, stats=st, a16=a16)
+        dy = torch.randn(B, Co, H, W, generator=gen)
+        gw = torch.empty_like(wd.permute(0, 2, 3, 1).contiguous()).permute(0, 3, 1, 2)
+        gb = torch.empty(Co, device="cuda")
+        ops.conv_wgrad(_nhwc(dy), xd, "c3", gw, gb, xf=ops.XF_AFFINE_SILU, stats=st, x16=a16)
+    finally:
+        ops.PROFILER = None
+    names = [r[0] for r in prof.records]
+    assert names[0].startswith("conv3_tile_bf16_kernel") and names[0].endswith(",true>"), names
+    assert names[1].startswith("wgrad3_tile_bf16_kernel") and names[1].endswith(",true>"), names
+    assert _rel(_nchw(y), F.conv2d(img, _r16(w), None, 1, 1)) < 2e-5
+    wr = w.clone().requires_grad_(True)
+    F.conv2d(img, wr, None, 1, 1).backward(_r16(dy))
+    assert _rel(gw.cpu(), wr.grad) < 3e-5
+    assert _rel(gb.cpu(), dy.sum(dim=(0, 2, 3))) < 3e-5

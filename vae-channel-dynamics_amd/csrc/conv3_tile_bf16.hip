@@ -41,7 +41,7 @@ constexpr int SB = 3 * SB1;                 // weight stage: the 3 taps of one k
 
 struct TileId { int b, y0, x0, n0, lin; };
 
-template <bool DG, bool UP, int XF>
+template <bool DG, bool UP, int XF, bool A16>
 __global__ __launch_bounds__(NT, 2) void conv3_tile_bf16_kernel(vae_igemm_args p, int tiles_x, int tiles_y, int ntiles) {
   constexpr int LDB = DG ? LDBN : LDBK;
   __shared__ __attribute__((aligned(16))) u16 smem[SH + 2 * SB];
@@ -86,6 +86,9 @@ __global__ __launch_bounds__(NT, 2) void conv3_tile_bf16_kernel(vae_igemm_args p
 
   // ---- operand staging (register-staged) ----
   constexpr int NW = 3 * BN * BK / 8 / NT;  // 6 uint4 of bf16 weights per thread and step
+  // with a bf16 activation image (A16) a slot is 8 channels = one 16-byte load, written to LDS as it is
+  constexpr int HQ16 = HP * (BK / 8), HI16 = (HQ16 + NT - 1) / NT;  // 816 slots, 4 per thread
+  uint4 rh16[A16 ? HI16 : 1];
   f32x4 rh[HI];                             // halo slots in flight (fp32, as loaded)
   uint2 rhp[HI];                            // the same slots transformed and rounded to bf16, waiting for the barrier
   uint4 rw[NW];                             // weight stage in flight
@@ -98,6 +101,22 @@ __global__ __launch_bounds__(NT, 2) void conv3_tile_bf16_kernel(vae_igemm_args p
   auto load_halo = [&](const TileId& id, int c0, bool valid) {
     const unsigned Hv = valid ? (unsigned)Hb : 0u;  // an invalid request: every row out of range (no branch on `valid`)
     const int ltid = opaque(tid), hk4 = ltid & (BK / 4 - 1);  // the thread's 4 channels: same for all its slots
+    if (A16) {
+      const int hk8 = ltid & (BK / 8 - 1);
+      const int c8 = c0 + hk8 * 8;
+      const auto rsA16 = VAE_BUF_RSRC(reinterpret_cast<const u16*>(p.A16) + (int64_t)id.b * g.Hs * g.Ws * g.Cs, img_bytes / 2);
+#pragma unroll
+      for (int i = 0; i < HI16; ++i) {
+        const int q = ltid + NT * i;
+        const int pp = q / (BK / 8);
+        const int ir = pp / HW_, jc = pp - ir * HW_;
+        const int hy = id.y0 - 1 + ir, hx = id.x0 - 1 + jc;
+        const bool ok = (q < HQ16) && ((unsigned)hy < Hv) && ((unsigned)hx < (unsigned)Wb) && (c8 < p.K);
+        const int sy = UP ? (hy >> 1) : hy, sx = UP ? (hx >> 1) : hx;
+        rh16[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsA16, ok ? (unsigned)(((sy * g.Ws + sx) * g.Cs + c8) * 2) : BUF_OOB, 0, 0));
+      }
+      return;
+    }
     hmask = 0;
     const int c = c0 + hk4 * 4;
     const auto rsA = VAE_BUF_RSRC(p.A + (int64_t)id.b * g.Hs * g.Ws * g.Cs, img_bytes);
@@ -123,6 +142,7 @@ __global__ __launch_bounds__(NT, 2) void conv3_tile_bf16_kernel(vae_igemm_args p
   // element) issue between that group's MFMAs and run while the matrix pipe works; behind the barrier only the
   // ds_writes remain
   auto xform_slot = [&](int i) {
+    if (A16) return;  // nothing to transform: the image holds the transformed, rounded operand
     f32x4 v = rh[i];
     if (XF != VAE_XF_NONE) {  // padding must stay zero AFTER the transform
       const bool ok = (hmask >> i) & 1;
@@ -140,6 +160,15 @@ __global__ __launch_bounds__(NT, 2) void conv3_tile_bf16_kernel(vae_igemm_args p
     for (int i = 0; i < HI; ++i) xform_slot(i);
   };
   auto write_halo = [&]() {
+    if (A16) {
+      const int ltid = opaque(tid), hk8 = ltid & (BK / 8 - 1);
+#pragma unroll
+      for (int i = 0; i < HI16; ++i) {
+        const int q = ltid + NT * i;
+        if (q < HQ16) *reinterpret_cast<uint4*>(&sH[(q / (BK / 8)) * LDH + hk8 * 8]) = rh16[i];
+      }
+      return;
+    }
     const int ltid = opaque(tid), hk4 = ltid & (BK / 4 - 1);
 #pragma unroll
     for (int i = 0; i < HI; ++i) {
@@ -314,10 +343,14 @@ __global__ __launch_bounds__(NT, 2) void conv3_tile_bf16_kernel(vae_igemm_args p
 
 template <bool DG, bool UP>
 void launch_xf(const vae_igemm_args& a, dim3 grid, int tx, int ty, int nt, hipStream_t st) {
+  if (a.A16 != nullptr) {  // transformed bf16 activation image (xf == NONE checked by the caller)
+    hipLaunchKernelGGL((conv3_tile_bf16_kernel<DG, UP, VAE_XF_NONE, true>), grid, dim3(NT), 0, st, a, tx, ty, nt);
+    return;
+  }
   switch (a.xf) {
-    case VAE_XF_NONE: hipLaunchKernelGGL((conv3_tile_bf16_kernel<DG, UP, VAE_XF_NONE>), grid, dim3(NT), 0, st, a, tx, ty, nt); break;
-    case VAE_XF_AFFINE: hipLaunchKernelGGL((conv3_tile_bf16_kernel<DG, UP, VAE_XF_AFFINE>), grid, dim3(NT), 0, st, a, tx, ty, nt); break;
-    default: hipLaunchKernelGGL((conv3_tile_bf16_kernel<DG, UP, VAE_XF_AFFINE_SILU>), grid, dim3(NT), 0, st, a, tx, ty, nt); break;
+    case VAE_XF_NONE: hipLaunchKernelGGL((conv3_tile_bf16_kernel<DG, UP, VAE_XF_NONE, false>), grid, dim3(NT), 0, st, a, tx, ty, nt); break;
+    case VAE_XF_AFFINE: hipLaunchKernelGGL((conv3_tile_bf16_kernel<DG, UP, VAE_XF_AFFINE, false>), grid, dim3(NT), 0, st, a, tx, ty, nt); break;
+    default: hipLaunchKernelGGL((conv3_tile_bf16_kernel<DG, UP, VAE_XF_AFFINE_SILU, false>), grid, dim3(NT), 0, st, a, tx, ty, nt); break;
   }
 }
 

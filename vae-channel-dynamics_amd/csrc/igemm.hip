@@ -646,6 +646,24 @@ static bool rows_use_tile_bf16(const vae_igemm_args& a, bool vec, bool bkm) {
   return a.prec == VAE_PREC_BF16 && rows_use_tile(a, vec, bkm) && conv3_tile_bf16_packed(a);
 }
 
+// both the forward and the wgrad of this 3x3 stride-1 layer run on the bf16 halo-tile kernels (which can read a bf16
+// activation image); pointers are placeholders with the alignment the real ones must have
+extern "C" int vae_bf16_act_image_ok(const vae_conv_geom* gp, int32_t Cout, int32_t Cin) {
+  if (!gp || getenv("VAEHIP_FLAT_CONV") || getenv("VAEHIP_NO_ACT16")) return 0;
+  const vae_conv_geom& g = *gp;
+  if (g.mode != VAE_MODE_FWD || Cin % 8 != 0 || g.Cs != Cin) return 0;
+  static const float dummy[4] __attribute__((aligned(16))) = {0.f, 0.f, 0.f, 0.f};
+  vae_igemm_args f{};
+  f.A = f.W = dummy; f.C = const_cast<float*>(dummy); f.Wh = dummy;
+  f.g = g; f.M = g.B * g.Ho * g.Wo; f.N = Cout; f.K = Cin; f.ldc = Cout;
+  f.sn = (int64_t)g.taps * Cin; f.sk = 1; f.st = Cin; f.batch = 1; f.alpha = 1.f; f.prec = VAE_PREC_BF16; f.xf = VAE_XF_NONE;
+  if (!rows_use_tile_bf16(f, rows_vec(f, false), false)) return 0;
+  vae_wgrad_args w{};
+  w.dY = w.X = dummy; w.g = g; w.M = Cout; w.N = Cin; w.ldy = Cout; w.npix = f.M; w.nsplit = 1; w.batch = 1; w.alpha = 1.f;
+  w.prec = VAE_PREC_BF16; w.xf = VAE_XF_NONE;
+  return wgrad_use_tile_bf16(w) ? 1 : 0;
+}
+
 // name of the kernel instantiation vae_igemm_rows / vae_wgrad dispatch to for these arguments
 // (profiling labels that match the rocprofv3 kernel names; no launch)
 extern "C" int vae_igemm_kernel_name(const vae_igemm_args* ap, char* buf, int32_t n) {
@@ -654,7 +672,8 @@ extern "C" int vae_igemm_kernel_name(const vae_igemm_args* ap, char* buf, int32_
   const bool bkm = rows_bkm(a), vec = rows_vec(a, bkm);
   const char* tf[2] = {"false", "true"};
   if (rows_use_tile_bf16(a, vec, bkm))
-    snprintf(buf, n, "conv3_tile_bf16_kernel<%s,%s,%d>", tf[a.g.mode == VAE_MODE_DGRAD], tf[a.g.mode == VAE_MODE_UP2X], a.xf);
+    snprintf(buf, n, "conv3_tile_bf16_kernel<%s,%s,%d,%s>", tf[a.g.mode == VAE_MODE_DGRAD], tf[a.g.mode == VAE_MODE_UP2X], a.xf,
+             tf[a.A16 != nullptr]);
   else if (a.prec != VAE_PREC_BF16 && rows_use_tile(a, vec, bkm))
     snprintf(buf, n, "conv3_tile_kernel<%s,%s,%s,%d>", tf[bkm], tf[a.g.mode == VAE_MODE_DGRAD], tf[a.g.mode == VAE_MODE_UP2X], a.xf);
   else if (a.prec == VAE_PREC_BF16 && vec)
@@ -670,7 +689,7 @@ extern "C" int vae_wgrad_kernel_name(const vae_wgrad_args* ap, char* buf, int32_
   const vae_wgrad_args& a = *ap;
   const bool vec = wgrad_vec(a);
   const char* tf[2] = {"false", "true"};
-  if (wgrad_use_tile_bf16(a)) snprintf(buf, n, "wgrad3_tile_bf16_kernel<%s,%d>", tf[a.g.mode == VAE_MODE_UP2X], a.xf);
+  if (wgrad_use_tile_bf16(a)) snprintf(buf, n, "wgrad3_tile_bf16_kernel<%s,%d,%s>", tf[a.g.mode == VAE_MODE_UP2X], a.xf, tf[a.X16 != nullptr]);
   else if (wgrad_use_tile(a)) snprintf(buf, n, "wgrad3_tile_kernel<%s,%d>", tf[a.g.mode == VAE_MODE_UP2X], a.xf);
   else if (a.prec == VAE_PREC_BF16 && vec)
     snprintf(buf, n, "wgrad_bf16_kernel<%s,%d>", a.M <= 32 ? "32,128,1,4" : (a.N <= 32 ? "128,32,4,1" : "128,128,4,2"), a.xf);
@@ -696,6 +715,8 @@ extern "C" int vae_igemm_rows(const vae_igemm_args* ap, void* stream) {
   const bool bkm = rows_bkm(a);
   const bool vec = rows_vec(a, bkm);
   hipStream_t st = (hipStream_t)stream;
+  VAE_CHECK(a.A16 == nullptr || (a.xf == VAE_XF_NONE && rows_use_tile_bf16(a, vec, bkm) && aligned16(a.A16) && a.g.Cs % 8 == 0),
+            "igemm_rows: A16 needs bf16 mode, xf == NONE and a layer vae_bf16_act_image_ok accepts");
   if (rows_use_tile_bf16(a, vec, bkm)) {
     if (int rc2 = launch_conv3_tile_bf16(a, bkm, st)) return rc2;
     VAE_LAUNCH_CHECK("conv3_tile_bf16");
@@ -740,6 +761,8 @@ extern "C" int vae_wgrad(const vae_wgrad_args* ap, void* stream) {
   const bool vec = wgrad_vec(a);
   hipStream_t st = (hipStream_t)stream;
   VAE_CHECK(a.prec == VAE_PREC_F32 || a.prec == VAE_PREC_BF16, "wgrad: bad prec %d", a.prec);
+  VAE_CHECK(a.X16 == nullptr || (a.xf == VAE_XF_NONE && wgrad_use_tile_bf16(a) && aligned16(a.X16) && a.g.Cs % 8 == 0),
+            "wgrad: X16 needs bf16 mode, xf == NONE and a layer vae_bf16_act_image_ok accepts");
   if (wgrad_use_tile_bf16(a)) {
     VAE_CHECK(a.nsplit <= 65535, "wgrad: nsplit too large");
     if (int rc2 = launch_wgrad3_tile_bf16(a, st)) return rc2;

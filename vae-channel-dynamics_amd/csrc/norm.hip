@@ -109,6 +109,32 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
   }
 }
 
+// same transform, output rounded to bf16 (the activation image the bf16 conv / wgrad kernels read): 8 elements per thread
+__global__ __launch_bounds__(256) void gn_apply_bf16_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, int64_t n8, int HWQ, int Q,
+                                                            int C, int xf, unsigned short* __restrict__ y) {
+  typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (; i < n8; i += stride) {
+    const int b = (int)(i / HWQ);
+    const int c = (int)(i % Q) * 8;
+    bf16x8_t h;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 8 + half * 4);
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + (int64_t)b * C + c + half * 4);
+      const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + (int64_t)b * C + c + half * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float u = v[e] * sc[e] + sh[e];
+        h[half * 4 + e] = (__bf16)((xf == VAE_XF_AFFINE_SILU) ? silu_f(u) : u);
+      }
+    }
+    *reinterpret_cast<uint4*>(y + i * 8) = __builtin_bit_cast(uint4, h);
+  }
+}
+
 __global__ __launch_bounds__(256) void gn_track_partial_kernel(const float* __restrict__ x,
                                                                const float* __restrict__ scale,
                                                                const float* __restrict__ shift, int HW, int C,
@@ -337,6 +363,18 @@ extern "C" int vae_gn_apply(const float* x, const float* scale, const float* shi
   hipLaunchKernelGGL(gn_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, n4, HW * Q, Q,
                      C, xf, y);
   VAE_LAUNCH_CHECK("gn_apply");
+  return VAE_OK;
+}
+
+extern "C" int vae_gn_apply_bf16(const float* x, const float* scale, const float* shift, int32_t B, int32_t HW, int32_t C,
+                                 int32_t xf, void* y16, void* stream) {
+  VAE_CHECK(x && scale && shift && y16 && B > 0 && HW > 0 && C > 0 && C % 8 == 0, "gn_apply_bf16: bad args (C %% 8 == 0)");
+  VAE_CHECK(aligned16(x) && aligned16(y16) && aligned16(scale) && aligned16(shift), "gn_apply_bf16: unaligned");
+  const int Q = C / 8;
+  const int64_t n8 = (int64_t)B * HW * Q;
+  hipLaunchKernelGGL(gn_apply_bf16_kernel, dim3(ew_blocks(n8)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, n8,
+                     HW * Q, Q, C, xf, reinterpret_cast<unsigned short*>(y16));
+  VAE_LAUNCH_CHECK("gn_apply_bf16");
   return VAE_OK;
 }
 

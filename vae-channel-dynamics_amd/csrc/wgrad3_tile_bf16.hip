@@ -28,7 +28,7 @@ constexpr int HQ = HPX * (BNT / 4);             // halo float4 slots (2176)
 constexpr int HI = (HQ + NT - 1) / NT;          // 3
 
 
-template <bool UP, int XF>
+template <bool UP, int XF, bool X16>
 __global__ __launch_bounds__(NT) void wgrad3_tile_bf16_kernel(vae_wgrad_args p, int tiles_x, int tiles_y, int64_t nunits) {
   constexpr int SSB = (XF != VAE_XF_NONE) ? 2 * SS_HALF * 2 : 0;
   __shared__ __attribute__((aligned(16))) u16 smem[2 * STAGE + SSB];
@@ -69,6 +69,9 @@ __global__ __launch_bounds__(NT) void wgrad3_tile_bf16_kernel(vae_wgrad_args p, 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][ni][r] = 0.f;
 
+  // with a bf16 activation image (X16) a halo slot is 8 channels = one 16-byte load, written to LDS as it is
+  constexpr int HQ16 = HPX * (BNT / 8), HI16 = (HQ16 + NT - 1) / NT;  // 1088 slots, 2 per thread
+  uint4 rh16[X16 ? HI16 : 1];
   f32x4 ra[AI], rh[HI];
   int hb = 0, hmask = 0;
   f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
@@ -115,6 +118,21 @@ __global__ __launch_bounds__(NT) void wgrad3_tile_bf16_kernel(vae_wgrad_args p, 
       const int c = m0 + a4 * 4;
       ra[i] = VAE_BUF_LOAD4(rsY, (q < AQv && c < p.M) ? (unsigned)((pix * p.ldy + c) * 4) : BUF_OOB);
     }
+    if (X16) {
+      const auto rsX16 = VAE_BUF_RSRC(reinterpret_cast<const u16*>(p.X16) + (int64_t)b * g.Hs * g.Ws * g.Cs, (size_t)g.Hs * g.Ws * g.Cs * 2u);
+#pragma unroll
+      for (int i = 0; i < HI16; ++i) {
+        const int q = tid + NT * i;
+        const int pp = q >> 3, k8 = q & 7;
+        const int ir = pp / HWD, jc = pp - ir * HWD;
+        const int hy = y0 - 1 + ir, hx = x0 - 1 + jc;
+        const bool ok = (q < HQ16) && ((unsigned)hy < Hv) && ((unsigned)hx < (unsigned)Wb);
+        const int sy = UP ? (hy >> 1) : hy, sx = UP ? (hx >> 1) : hx;
+        const int c = n0 + k8 * 8;
+        rh16[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsX16, (ok && c < p.N) ? (unsigned)(((sy * g.Ws + sx) * g.Cs + c) * 2) : BUF_OOB, 0, 0));
+      }
+      return;
+    }
     hb = b;
     hmask = 0;
 #pragma unroll
@@ -140,6 +158,14 @@ __global__ __launch_bounds__(NT) void wgrad3_tile_bf16_kernel(vae_wgrad_args p, 
         *reinterpret_cast<uint2*>(&sA[(q >> 5) * LDA + a4 * 4]) = pack4(ra[i]);
         if (do_bias) bsum += ra[i];
       }
+    }
+    if (X16) {
+#pragma unroll
+      for (int i = 0; i < HI16; ++i) {
+        const int q = tid + NT * i;
+        if (q < HQ16) *reinterpret_cast<uint4*>(&sH[(q >> 3) * LDH + (q & 7) * 8]) = rh16[i];
+      }
+      return;
     }
 #pragma unroll
     for (int i = 0; i < HI; ++i) {
@@ -260,7 +286,12 @@ int launch_wgrad3_tile_bf16(const vae_wgrad_args& a, hipStream_t st) {
   const int64_t nunits = wgrad3_tile_bf16_units(g);
   dim3 grid((unsigned)wgrad3_tile_bf16_columns(a), (unsigned)a.nsplit, 1);
   const bool up = g.mode == VAE_MODE_UP2X;
-#define WG3(UPV, XFV) hipLaunchKernelGGL((wgrad3_tile_bf16_kernel<UPV, XFV>), grid, dim3(NT), 0, st, a, tx, ty, nunits)
+#define WG3(UPV, XFV) hipLaunchKernelGGL((wgrad3_tile_bf16_kernel<UPV, XFV, false>), grid, dim3(NT), 0, st, a, tx, ty, nunits)
+  if (a.X16 != nullptr) {  // transformed bf16 activation image (xf == NONE checked by the caller)
+    if (up) hipLaunchKernelGGL((wgrad3_tile_bf16_kernel<true, VAE_XF_NONE, true>), grid, dim3(NT), 0, st, a, tx, ty, nunits);
+    else hipLaunchKernelGGL((wgrad3_tile_bf16_kernel<false, VAE_XF_NONE, true>), grid, dim3(NT), 0, st, a, tx, ty, nunits);
+    return 0;
+  }
   switch (a.xf) {
     case VAE_XF_NONE: if (up) WG3(true, VAE_XF_NONE); else WG3(false, VAE_XF_NONE); break;
     case VAE_XF_AFFINE: if (up) WG3(true, VAE_XF_AFFINE); else WG3(false, VAE_XF_AFFINE); break;

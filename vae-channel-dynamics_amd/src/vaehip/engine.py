@@ -44,6 +44,9 @@ class Engine:
         self._ident: Dict[tuple, Stats] = {}
         self.precision = ops.PREC_F32  # arithmetic of the conv contractions (set_precision)
         self._flat16: Optional[torch.Tensor] = None  # bf16 image of the parameter arena (bf16 mode)
+        # bf16 mode: bf16 images of GroupNorm+SiLU'd conv inputs, kept from a recording forward for that layer's wgrad
+        self._a16: Dict[int, torch.Tensor] = {}
+        self._keep16 = False
         # activation checkpointing of the decoder (BASELINE config 5): every resnet / attention / sampler of the decoder
         # keeps only its input; its forward is run again (recording) right before its own backward
         self.checkpoint_decoder = False
@@ -197,7 +200,13 @@ class Engine:
         if sinks:
             ho, wo = ops.out_hw(kind, x.shape[1], x.shape[2])
             tb = ops.conv_track_buffer(x.shape[0] * ho * wo, m.weight.shape[0], x.device)
-        y = ops.conv_fwd(x, m.weight, m.bias, kind, xf=xf, stats=st, res=res if fuse_res else None, track=tb)
+        a16 = None
+        if xf != XF_NONE and ops.act_image_ok(kind, x.shape, m.weight.shape[0], m.weight.shape[1]):
+            # transform and round once (2 B/element written); forward and wgrad then read the image and transform nothing
+            a16 = ops.gn_apply_bf16(x, st, xf)
+            if self._keep16:
+                self._a16[id(m)] = a16
+        y = ops.conv_fwd(x, m.weight, m.bias, kind, xf=xf, stats=st, res=res if fuse_res else None, track=tb, a16=a16)
         if sinks:
             v = ops.track_final(tb, y.shape[0] * y.shape[1] * y.shape[2])
             for s in sinks:
@@ -210,7 +219,7 @@ class Engine:
 
     def _conv_bwd(self, m, x, dy, xf, st, need_dx=True):
         kind = getattr(m, "kind", "c1")
-        ops.conv_wgrad(dy, x, kind, self._g(m.weight), self._g(m.bias), xf=xf, stats=st)
+        ops.conv_wgrad(dy, x, kind, self._g(m.weight), self._g(m.bias), xf=xf, stats=st, x16=self._a16.pop(id(m), None))
         if need_dx:
             return ops.conv_dgrad(dy, m.weight, kind, (x.shape[1], x.shape[2]))
         return None
@@ -254,6 +263,7 @@ class Engine:
         self._no_hooks(r.nonlinearity, "ResnetBlock2D.nonlinearity")
         self._no_hooks(r.dropout, "ResnetBlock2D.dropout")
         self._pre(r, lambda: x)
+        self._keep16 = tape is not None
         st1 = self._gn(r.norm1, x)
         h = self._conv(r.conv1, x, XF_AFFINE_SILU, st1)
         st2 = self._gn(r.norm2, h)

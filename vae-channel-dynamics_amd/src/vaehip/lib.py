@@ -26,14 +26,14 @@ class IgemmArgs(C.Structure):
                 ("track", _fp), ("g", ConvGeom), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
                 ("ldc", C.c_int32), ("sn", C.c_int64), ("sk", C.c_int64), ("st", C.c_int64),
                 ("batch", C.c_int32), ("sAb", C.c_int64), ("sWb", C.c_int64), ("sCb", C.c_int64),
-                ("xf", C.c_int32), ("alpha", C.c_float), ("prec", C.c_int32), ("Wh", _fp)]
+                ("xf", C.c_int32), ("alpha", C.c_float), ("prec", C.c_int32), ("Wh", _fp), ("A16", _fp)]
 
 
 class WgradArgs(C.Structure):
     _fields_ = [("dY", _fp), ("X", _fp), ("out", _fp), ("partial", _fp), ("bias_partial", _fp), ("scale", _fp), ("shift", _fp),
                 ("g", ConvGeom), ("M", C.c_int32), ("N", C.c_int32), ("ldy", C.c_int32), ("npix", C.c_int32),
                 ("nsplit", C.c_int32), ("batch", C.c_int32), ("sYb", C.c_int64), ("sXb", C.c_int64),
-                ("sOb", C.c_int64), ("xf", C.c_int32), ("alpha", C.c_float), ("prec", C.c_int32)]
+                ("sOb", C.c_int64), ("xf", C.c_int32), ("alpha", C.c_float), ("prec", C.c_int32), ("X16", _fp)]
 
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
@@ -50,6 +50,8 @@ SIGNATURES = {
     "vae_gn_stats_partial": [vp, i32, i32, i32, i32, i32, vp, vp],
     "vae_gn_stats_final": [vp, i32, i32, i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp],
     "vae_gn_apply": [vp, vp, vp, i32, i32, i32, i32, vp, vp],
+    "vae_gn_apply_bf16": [vp, vp, vp, i32, i32, i32, i32, vp, vp],
+    "vae_bf16_act_image_ok": [C.POINTER(ConvGeom), i32, i32],
     "vae_gn_track_partial": [vp, vp, vp, i32, i32, i32, i32, vp, vp],
     "vae_track_final": [vp, i32, i32, f32, vp, vp],
     "vae_gn_bwd_partial": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp],

@@ -167,11 +167,32 @@ def _fwd_geom(kind: str, B: int, H: int, W: int, Cs: int) -> ConvGeom:
     raise ValueError(kind)
 
 
+def act_image_ok(kind: str, x_shape, Co: int, Ci: int) -> bool:
+    """bf16 mode: may this layer's forward and wgrad read a bf16 image of the transformed input (gn_apply_bf16)?"""
+    if PRECISION != PREC_BF16 or WEIGHTS16 is None or kind != "c3":
+        return False
+    B, H, W, Cs = x_shape
+    g = _fwd_geom(kind, B, H, W, Cs)
+    return bool(lib.query("vae_bf16_act_image_ok", C.byref(g), Co, Ci))
+
+
+def gn_apply_bf16(x: torch.Tensor, st: "Stats", xf: int) -> torch.Tensor:
+    """bf16(XF(x)) as a [B,H,W,C] bfloat16 tensor: the activation image conv_fwd(a16=) / conv_wgrad(x16=) read."""
+    B, H, W, Cc = x.shape
+    y = torch.empty((B, H, W, Cc), device=x.device, dtype=torch.bfloat16)
+    lib.call("vae_gn_apply_bf16", _p(x), _p(st.scale), _p(st.shift), B, H * W, Cc, xf, _p(y), _stream())
+    return y
+
+
 def conv_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], kind: str, *,
              xf: int = XF_NONE, stats: Optional[Stats] = None, res: Optional[torch.Tensor] = None,
-             track: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """x [B,H,W,Cs] (Cs >= Cin, extra channels must be zero-weighted i.e. Cin is taken from w)."""
+             track: Optional[torch.Tensor] = None, a16: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [B,H,W,Cs] (Cs >= Cin, extra channels must be zero-weighted i.e. Cin is taken from w).
+    a16: bf16 image of XF(x) (then xf / stats are not applied again; x only gives the geometry)."""
     _chk_c(x, "conv_fwd.x")
+    if a16 is not None:
+        assert a16.shape == x.shape and a16.dtype == torch.bfloat16 and a16.is_contiguous()
+        xf = XF_NONE
     wv = ohwi(w)
     Co, kh, kw, Ci = wv.shape
     B, H, W, Cs = x.shape
@@ -194,7 +215,7 @@ def conv_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], kin
     a.M, a.N, a.K, a.ldc = B * g.Ho * g.Wo, Co, Ci, Co
     a.sn, a.sk, a.st = taps * Ci, 1, Ci
     a.batch, a.sAb, a.sWb, a.sCb = 1, 0, 0, 0
-    a.xf, a.alpha, a.prec, a.Wh = xf, 1.0, PRECISION, _wh(wv)
+    a.xf, a.alpha, a.prec, a.Wh, a.A16 = xf, 1.0, PRECISION, _wh(wv), _p(a16)
     if track is not None:
         assert track.numel() >= ((a.M + 127) // 128) * Co
     _launch_igemm(a)
@@ -239,10 +260,15 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, kind: str, in_hw: Tuple[int, i
 
 
 def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, kind: str, wgrad_out: torch.Tensor,
-               bgrad_out: Optional[torch.Tensor], *, xf: int = XF_NONE, stats: Optional[Stats] = None):
-    """writes dW into `wgrad_out` (a view with the weight's OHWI memory) and db into `bgrad_out`."""
+               bgrad_out: Optional[torch.Tensor], *, xf: int = XF_NONE, stats: Optional[Stats] = None,
+               x16: Optional[torch.Tensor] = None):
+    """writes dW into `wgrad_out` (a view with the weight's OHWI memory) and db into `bgrad_out`.
+    x16: bf16 image of XF(x) (as conv_fwd's a16)."""
     _chk_c(dy, "conv_wgrad.dy")
     _chk_c(x, "conv_wgrad.x")
+    if x16 is not None:
+        assert x16.shape == x.shape and x16.dtype == torch.bfloat16 and x16.is_contiguous()
+        xf = XF_NONE
     gv = ohwi(wgrad_out)
     Co, kh, kw, Ci = gv.shape
     taps = kh * kw
@@ -255,7 +281,7 @@ def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, kind: str, wgrad_out: torch.Te
     a.g = g
     a.M, a.N, a.ldy, a.npix, a.nsplit = Co, Ci, Co, npix, 1
     a.batch, a.sYb, a.sXb, a.sOb = 1, 0, 0, 0
-    a.xf, a.alpha, a.prec = xf, 1.0, PRECISION
+    a.xf, a.alpha, a.prec, a.X16 = xf, 1.0, PRECISION, _p(x16)
     if xf != XF_NONE:
         assert stats is not None
         a.scale, a.shift = _p(stats.scale), _p(stats.shift)
