@@ -296,6 +296,12 @@ __global__ __launch_bounds__(NT, 2) void conv3_tile_bf16_kernel(vae_igemm_args p
     }
 
     // ---------------- epilogue (fp32); the stores drain under the next tile's main loop ----------------
+    // outputs and the residual go through buffer descriptors over this tile's image: a pixel / channel outside the
+    // tensor is an out-of-range offset (load reads 0, store is dropped), so the 16 residual loads of a block are issued
+    // back to back and there is no branch per element
+    const size_t obytes = (size_t)g.Ho * g.Wo * p.ldc * 4u;
+    const auto rsC = VAE_BUF_RSRC(p.C + (int64_t)cur.b * g.Ho * g.Wo * p.ldc, obytes);
+    const auto rsR = VAE_BUF_RSRC((p.res ? p.res : p.C) + (int64_t)cur.b * g.Ho * g.Wo * p.ldc, obytes);
     float tsum[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
@@ -303,18 +309,25 @@ __global__ __launch_bounds__(NT, 2) void conv3_tile_bf16_kernel(vae_igemm_args p
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
         const int col = cur.n0 + wn * 64 + ni * 32 + lr;
-        const bool colok = col < p.N;
+        const bool colok = col < p.N && oy < g.Ho;
         const float bv = (p.bias && colok) ? p.bias[col] : 0.f;
+        unsigned off[16];
+        float rv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int ox = cur.x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (colok && oy < g.Ho && ox < g.Wo) {
-            const int64_t o = (((int64_t)cur.b * g.Ho + oy) * g.Wo + ox) * p.ldc + col;
-            float v = p.alpha * acc[mi][ni][r] + bv;
-            if (p.res) v += p.res[o];
-            p.C[o] = v;
-            tsum[mi][ni] += fabsf(v);
-          }
+          off[r] = (colok && ox < g.Wo) ? (unsigned)(((oy * g.Wo + ox) * p.ldc + col) * 4) : BUF_OOB;
+          rv[r] = 0.f;
+        }
+        if (p.res) {  // uniform
+#pragma unroll
+          for (int r = 0; r < 16; ++r) rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, off[r], 0, 0));
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = p.alpha * acc[mi][ni][r] + bv + rv[r];
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, off[r], 0, 0);
+          tsum[mi][ni] += (off[r] != BUF_OOB) ? fabsf(v) : 0.f;
           acc[mi][ni][r] = 0.f;
         }
       }
