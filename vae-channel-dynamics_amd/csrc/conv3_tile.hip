@@ -190,23 +190,35 @@ __global__ __launch_bounds__(NT) void conv3_tile_kernel(vae_igemm_args p, int ti
   }
 
   // ---------------- epilogue ----------------
+  // outputs and the residual through buffer descriptors over this tile's image: out-of-range = load 0 / store dropped,
+  // so the 16 residual loads of a block are issued back to back and there is no branch per element
   const int oy = y0 + wm;
+  const size_t obytes = (size_t)g.Ho * g.Wo * p.ldc * 4u;
+  const auto rsC = VAE_BUF_RSRC(p.C + (int64_t)b * g.Ho * g.Wo * p.ldc, obytes);
+  const auto rsR = VAE_BUF_RSRC((p.res ? p.res : p.C) + (int64_t)b * g.Ho * g.Wo * p.ldc, obytes);
   float tsum[2] = {0.f, 0.f};
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
     const int col = n0 + wn * 64 + ni * 32 + lr;
-    const bool colok = col < p.N;
+    const bool colok = col < p.N && oy < g.Ho;
     const float bv = (p.bias && colok) ? p.bias[col] : 0.f;
+    unsigned off[16];
+    float rv[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int ox = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (colok && oy < g.Ho && ox < g.Wo) {
-        const int64_t o = (((int64_t)b * g.Ho + oy) * g.Wo + ox) * p.ldc + col;
-        float v = p.alpha * acc[ni][r] + bv;
-        if (p.res) v += p.res[o];
-        p.C[o] = v;
-        tsum[ni] += fabsf(v);
-      }
+      off[r] = (colok && ox < g.Wo) ? (unsigned)(((oy * g.Wo + ox) * p.ldc + col) * 4) : BUF_OOB;
+      rv[r] = 0.f;
+    }
+    if (p.res) {  // uniform
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, off[r], 0, 0));
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = p.alpha * acc[ni][r] + bv + rv[r];
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, off[r], 0, 0);
+      tsum[ni] += (off[r] != BUF_OOB) ? fabsf(v) : 0.f;
     }
   }
   if (p.track) {
@@ -238,7 +250,7 @@ bool conv3_tile_eligible(const vae_igemm_args& a, bool vec, bool bkm) {
   const vae_conv_geom& g = a.g;
   if (!vec || a.batch != 1 || g.taps != 9 || g.stride != 1 || g.pad_t != 1 || g.pad_l != 1) return false;
   if (a.N <= 32 || a.K % 4 != 0 || a.alpha != 1.0f) return false;
-  if ((size_t)g.Hs * g.Ws * g.Cs * 4u >= BUF_MAX) return false;  // one image per activation descriptor
+  if ((size_t)g.Hs * g.Ws * g.Cs * 4u >= BUF_MAX || (size_t)g.Ho * g.Wo * a.ldc * 4u >= BUF_MAX) return false;  // one image per descriptor
   if ((size_t)std::max((int64_t)a.K * a.sk, (int64_t)a.N * a.sn) * 4u >= BUF_MAX) return false;
   if (g.Wo % TW != 0 || g.Ho % TH != 0) return false;
   if (a.xf != VAE_XF_NONE && (a.K > SS_HALF || bkm)) return false;

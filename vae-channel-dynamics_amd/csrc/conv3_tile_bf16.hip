@@ -373,7 +373,7 @@ void launch_xf(const vae_igemm_args& a, dim3 grid, int tx, int ty, int nt, hipSt
 // straddle a row end
 bool conv3_tile_bf16_packed(const vae_igemm_args& a) {
   const vae_conv_geom& g = a.g;
-  const bool fits32 = (size_t)g.Hs * g.Ws * g.Cs * 4u < BUF_MAX &&  // one image per activation descriptor
+  const bool fits32 = (size_t)g.Hs * g.Ws * g.Cs * 4u < BUF_MAX && (size_t)g.Ho * g.Wo * a.ldc * 4u < BUF_MAX &&  // one image per descriptor
                       (size_t)std::max((int64_t)a.K * a.sk, (int64_t)a.N * a.sn) * 2u < BUF_MAX;
   return a.Wh != nullptr && aligned16(a.Wh) && aligned16(a.A) && fits32 && a.K % 8 == 0 && a.N % 8 == 0 && a.st % 8 == 0 &&
          (a.sn == 1 || a.sn % 8 == 0) && (a.sk == 1 || a.sk % 8 == 0);
