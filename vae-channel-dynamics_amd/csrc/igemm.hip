@@ -265,8 +265,12 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_rows_kernel(vae_igemm_args
   }
 
   // ---------------- epilogue ----------------
+  // outputs and the residual through buffer descriptors (common.h): a row / column outside the matrix is an
+  // out-of-range offset (load reads 0, store is dropped): no branch per element, residual loads issued back to back
   float* __restrict__ C = p.C + (int64_t)z * p.sCb;
-  const float* __restrict__ R = p.res ? p.res + (int64_t)z * p.sCb : nullptr;
+  const size_t obytes = (size_t)p.M * p.ldc * 4u;
+  const auto rsC = VAE_BUF_RSRC(C, obytes);
+  const auto rsR = VAE_BUF_RSRC(p.res ? p.res + (int64_t)z * p.sCb : C, obytes);
   float tsum[NI];
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) tsum[ni] = 0.f;
@@ -277,22 +281,29 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_rows_kernel(vae_igemm_args
     const float bv = (p.bias && colok) ? p.bias[col] : 0.f;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
+      unsigned off[16];
+      float rv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * TM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (colok && row < p.M) {
-          float v = p.alpha * acc[mi][ni][r] + bv;
-          int64_t orow = row;
-          if (s2c) {  // class-major row -> pixel-major output row
-            int b, y, x;
-            row_pixel(row, b, y, x);
-            orow = ((int64_t)b * g.Ho + y) * g.Wo + x;
-          }
-          const int64_t o = orow * p.ldc + col;
-          if (R) v += R[o];
-          C[o] = v;
-          tsum[ni] += fabsf(v);
+        unsigned orow = (unsigned)row;
+        if (s2c) {  // class-major row -> pixel-major output row
+          int b, y, x;
+          row_pixel(row < p.M ? row : m0, b, y, x);
+          orow = (unsigned)((b * g.Ho + y) * g.Wo + x);
         }
+        off[r] = (colok && row < p.M) ? (orow * (unsigned)p.ldc + (unsigned)col) * 4u : BUF_OOB;
+        rv[r] = 0.f;
+      }
+      if (p.res) {  // uniform
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, off[r], 0, 0));
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = p.alpha * acc[mi][ni][r] + bv + rv[r];
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, off[r], 0, 0);
+        tsum[ni] += (off[r] != BUF_OOB) ? fabsf(v) : 0.f;
       }
     }
   }
@@ -706,6 +717,7 @@ extern "C" int vae_igemm_rows(const vae_igemm_args* ap, void* stream) {
   VAE_CHECK(a.K <= a.g.Cs, "igemm_rows: K=%d exceeds source channels %d", a.K, a.g.Cs);
   VAE_CHECK((int64_t)a.g.B * a.g.Ho * a.g.Wo == a.M, "igemm_rows: M=%d != B*Ho*Wo", a.M);
   VAE_CHECK(a.ldc >= a.N, "igemm_rows: ldc < N");
+  VAE_CHECK((size_t)a.M * a.ldc * 4u < BUF_MAX, "igemm_rows: output too large for 32-bit byte offsets");
   VAE_CHECK(a.prec == VAE_PREC_F32 || a.prec == VAE_PREC_BF16, "igemm_rows: bad prec %d", a.prec);
   VAE_CHECK(a.sk == 1 || a.sn == 1, "igemm_rows: one of sn, sk must be 1 (sn=%lld sk=%lld)", (long long)a.sn,
             (long long)a.sk);
