@@ -136,9 +136,12 @@ __global__ __launch_bounds__(NT) void conv3_tile_kernel(vae_igemm_args p, int ti
     }
   };
 
-  auto compute = [&](const float* sA, const float* sB, int kk) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(&sA[kk * 8 + lh * 4]);
-    f32x4 bq[2];
+  // k-group kk = 8 channels: one halo fragment and two weight fragments feed 8 MFMAs.  The fragments of k-group kk+1
+  // are requested before the MFMAs of kk are issued (pinned with sched_barrier; hipcc otherwise puts the reads right in
+  // front of their MFMAs and waits for them there).
+  f32x4 fa[2], fb[2][2];
+  auto fetch = [&](const float* sA, const float* sB, int kk, f32x4& a, f32x4* bq) {
+    a = *reinterpret_cast<const f32x4*>(&sA[kk * 8 + lh * 4]);
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
       if (!BKM) {
@@ -148,13 +151,18 @@ __global__ __launch_bounds__(NT) void conv3_tile_kernel(vae_igemm_args p, int ti
         for (int j = 0; j < 4; ++j) bq[ni][j] = sB[(kk * 8 + lh * 4 + j) * LDB + wn * 64 + ni * 32 + lr];
       }
     }
+  };
+  auto compute = [&](const float* sA, const float* sB, int kk) {  // fragments of kk already requested
+    if (kk + 1 < BK / 8) fetch(sA, sB, kk + 1, fa[(kk + 1) & 1], fb[(kk + 1) & 1]);
+    __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni)
-        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bq[ni][j], acc[ni], 0, 0, 0);
+        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][j], fb[kk & 1][ni][j], acc[ni], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
   };
 
   load_halo(0);
@@ -171,6 +179,7 @@ __global__ __launch_bounds__(NT) void conv3_tile_kernel(vae_igemm_args p, int ti
     const float* cA = sH + ((wm + dy) * HW_ + lr + dx) * LDA;
     const float* cB = sBst + (s & 1) * SB;
     if (tap == 0 && cch + 1 < kchunks) load_halo((cch + 1) * BK);  // lands during this chunk's 9 taps
+    fetch(cA, cB, 0, fa[0], fb[0]);
     compute(cA, cB, 0);
     compute(cA, cB, 1);
     if (s + 1 < steps) {

@@ -129,18 +129,30 @@ __global__ __launch_bounds__(NT) void wgrad3_tile_kernel(vae_wgrad_args p, int x
       }
     }
   };
-  auto compute = [&](const float* sA, const float* sH, int kk) {  // 8 pixels of unit row kk / 4
+  // k-group kk = 8 pixels of unit row kk / 4: 4 dY values and 3 taps x 4 halo values per lane feed 12 MFMAs.  The
+  // operands of k-group kk+1 are requested before the MFMAs of kk are issued (pinned with sched_barrier: hipcc otherwise
+  // interleaves reads and MFMAs with a full lgkmcnt(0) wait in front of every few MFMAs).
+  float fa[2][4], fb[2][3][4];
+  auto fetch = [&](const float* sA, const float* sH, int kk, float* a, float (*bq)[4]) {
     const int r = kk / (TW / 8), c0 = (kk % (TW / 8)) * 8;
-    float a[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) a[j] = sA[(kk * 8 + lh * 4 + j) * LDA + mt * 32 + lr];
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {  // tap (kh = tg, kw = t): halo pixel (r + kh, c + kw)
-      float bq[4];
+    for (int t = 0; t < 3; ++t)  // tap (kh = tg, kw = t): halo pixel (r + kh, c + kw)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bq[j] = sH[((r + tg) * HWD + c0 + lh * 4 + j + t) * LDH + lr];
+      for (int j = 0; j < 4; ++j) bq[t][j] = sH[((r + tg) * HWD + c0 + lh * 4 + j + t) * LDH + lr];
+  };
+  auto compute = [&](const float* sA, const float* sH, int k0, int k1) {  // k-groups [k0, k1); k0 is already fetched
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bq[j], acc[t], 0, 0, 0);
+    for (int kk = k0; kk < k1; ++kk) {
+      if (kk + 1 < UPX / 8) fetch(sA, sH, kk + 1, fa[(kk + 1) & 1], fb[(kk + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][j], fb[kk & 1][t][j], acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
@@ -152,15 +164,14 @@ __global__ __launch_bounds__(NT) void wgrad3_tile_kernel(vae_wgrad_args p, int x
     __syncthreads();
     for (int s = 0; s < nu; ++s) {
       const float* cA = smem + (s & 1) * STAGE;
-#pragma unroll
-      for (int kk = 0; kk < UPX / 16; ++kk) compute(cA, cA + SA, kk);
+      fetch(cA, cA + SA, 0, fa[0], fb[0]);
+      compute(cA, cA + SA, 0, UPX / 16);
       if (s + 1 < nu) {  // staged in the shadow of the MFMAs already issued
         float* nA = smem + ((s + 1) & 1) * STAGE;
         store_lds(nA, nA + SA);
         if (s + 2 < nu) load_regs(ubeg + s + 2);
       }
-#pragma unroll
-      for (int kk = UPX / 16; kk < UPX / 8; ++kk) compute(cA, cA + SA, kk);
+      compute(cA, cA + SA, UPX / 16, UPX / 8);
       __syncthreads();
     }
   }
