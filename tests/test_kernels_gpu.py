@@ -412,8 +412,10 @@ def test_bf16_flat_conv_fwd_dgrad_wgrad(cuda, bf16_mode, kind, B, H, W, Ci, Co):
         ops.PROFILER = None
     names = [r[0] for r in prof.records]
     assert len(names) == 3
-    # channel counts that are not a multiple of 4 have no vectorised form and stay on the exact fp32 kernels
-    expect16 = [Ci % 4 == 0, Co % 4 == 0 and Ci % 4 == 0, Co % 4 == 0 and Ci % 4 == 0]
+    # channel counts that are not a multiple of 4 have no vectorised form and stay on the exact fp32 kernels; a <= 4-channel
+    # side puts the layer on the (exact fp32) VALU kernels of skinny.hip
+    expect16 = [Ci % 4 == 0 and Ci > 4, Co % 4 == 0 and Ci % 4 == 0 and Co > 4, Co % 4 == 0 and Ci % 4 == 0 and min(Ci, Co) > 4]
+    assert ("smallk" in names[0]) == (Ci <= 4) and ("smallk" in names[1]) == (Co <= 4) and ("smallk" in names[2]) == (min(Ci, Co) <= 4), names
     assert [("bf16" in n) for n in names] == expect16, names
     rf, rd, rw = [(_r16 if e else (lambda t: t)) for e in expect16]
     assert _rel(_nchw(y), _ref_conv(rf(x), rf(w), b, kind)) < 2e-5

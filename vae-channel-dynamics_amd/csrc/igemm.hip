@@ -29,6 +29,11 @@ bool wgrad3_tile_bf16_eligible(const vae_wgrad_args& a, bool vec);
 int64_t wgrad3_tile_bf16_units(const vae_conv_geom& g);
 int wgrad3_tile_bf16_columns(const vae_wgrad_args& a);
 int launch_wgrad3_tile_bf16(const vae_wgrad_args& a, hipStream_t st);
+bool conv_smallk_eligible(const vae_igemm_args& a);                      // skinny.hip (<= 4-channel sides on the VALU)
+int launch_conv_smallk(const vae_igemm_args& a, hipStream_t st);
+int wgrad_smallk_kind(const vae_wgrad_args& a);
+int wgrad_smallk_tiles(const vae_wgrad_args& a);
+int launch_wgrad_smallk(const vae_wgrad_args& a, hipStream_t st);
 int launch_rows_bf16(const vae_igemm_args& a, bool bkm, hipStream_t st);   // igemm_bf16.hip (vectorised shapes only)
 int launch_wgrad_bf16(const vae_wgrad_args& a, hipStream_t st);
 
@@ -617,6 +622,11 @@ extern "C" int vae_wgrad_plan(const vae_wgrad_args* ap, int32_t* nsplit, int32_t
     const int64_t per_max = std::max<int64_t>(1, (nb_max - 1) * upi);
     return (units + per_max - 1) / per_max;
   };
+  if (wgrad_smallk_kind(a)) {  // <= 4-channel side: one slab per workgroup, 128-pixel tiles dealt out in ranges
+    *nsplit = (int32_t)std::max(1, std::min(1024, wgrad_smallk_tiles(a)));
+    *xf_fusable = 1;
+    return VAE_OK;
+  }
   if (wgrad_use_tile_bf16(a)) {
     const int64_t units = wgrad3_tile_bf16_units(a.g);
     const int64_t cols = wgrad3_tile_bf16_columns(a);
@@ -682,7 +692,9 @@ extern "C" int vae_igemm_kernel_name(const vae_igemm_args* ap, char* buf, int32_
   const vae_igemm_args& a = *ap;
   const bool bkm = rows_bkm(a), vec = rows_vec(a, bkm);
   const char* tf[2] = {"false", "true"};
-  if (rows_use_tile_bf16(a, vec, bkm))
+  if (conv_smallk_eligible(a))
+    snprintf(buf, n, "conv_smallk_kernel");
+  else if (rows_use_tile_bf16(a, vec, bkm))
     snprintf(buf, n, "conv3_tile_bf16_kernel<%s,%s,%d,%s>", tf[a.g.mode == VAE_MODE_DGRAD], tf[a.g.mode == VAE_MODE_UP2X], a.xf,
              tf[a.A16 != nullptr]);
   else if (a.prec != VAE_PREC_BF16 && rows_use_tile(a, vec, bkm))
@@ -700,7 +712,8 @@ extern "C" int vae_wgrad_kernel_name(const vae_wgrad_args* ap, char* buf, int32_
   const vae_wgrad_args& a = *ap;
   const bool vec = wgrad_vec(a);
   const char* tf[2] = {"false", "true"};
-  if (wgrad_use_tile_bf16(a)) snprintf(buf, n, "wgrad3_tile_bf16_kernel<%s,%d,%s>", tf[a.g.mode == VAE_MODE_UP2X], a.xf, tf[a.X16 != nullptr]);
+  if (wgrad_smallk_kind(a)) snprintf(buf, n, "wgrad_smallk_kernel<%s,%d>", tf[wgrad_smallk_kind(a) == 1], a.xf);
+  else if (wgrad_use_tile_bf16(a)) snprintf(buf, n, "wgrad3_tile_bf16_kernel<%s,%d,%s>", tf[a.g.mode == VAE_MODE_UP2X], a.xf, tf[a.X16 != nullptr]);
   else if (wgrad_use_tile(a)) snprintf(buf, n, "wgrad3_tile_kernel<%s,%d>", tf[a.g.mode == VAE_MODE_UP2X], a.xf);
   else if (a.prec == VAE_PREC_BF16 && vec)
     snprintf(buf, n, "wgrad_bf16_kernel<%s,%d>", a.M <= 32 ? "32,128,1,4" : (a.N <= 32 ? "128,32,4,1" : "128,128,4,2"), a.xf);
@@ -727,6 +740,11 @@ extern "C" int vae_igemm_rows(const vae_igemm_args* ap, void* stream) {
   const bool bkm = rows_bkm(a);
   const bool vec = rows_vec(a, bkm);
   hipStream_t st = (hipStream_t)stream;
+  if (a.A16 == nullptr && conv_smallk_eligible(a)) {
+    if (int rc2 = launch_conv_smallk(a, st)) return rc2;
+    VAE_LAUNCH_CHECK("conv_smallk");
+    return VAE_OK;
+  }
   VAE_CHECK(a.A16 == nullptr || (a.xf == VAE_XF_NONE && rows_use_tile_bf16(a, vec, bkm) && aligned16(a.A16) && a.g.Cs % 8 == 0),
             "igemm_rows: A16 needs bf16 mode, xf == NONE and a layer vae_bf16_act_image_ok accepts");
   if (rows_use_tile_bf16(a, vec, bkm)) {
@@ -773,6 +791,12 @@ extern "C" int vae_wgrad(const vae_wgrad_args* ap, void* stream) {
   const bool vec = wgrad_vec(a);
   hipStream_t st = (hipStream_t)stream;
   VAE_CHECK(a.prec == VAE_PREC_F32 || a.prec == VAE_PREC_BF16, "wgrad: bad prec %d", a.prec);
+  if (a.X16 == nullptr && wgrad_smallk_kind(a)) {
+    VAE_CHECK(a.nsplit <= 65535, "wgrad: nsplit too large");
+    if (int rc2 = launch_wgrad_smallk(a, st)) return rc2;
+    VAE_LAUNCH_CHECK("wgrad_smallk");
+    return VAE_OK;
+  }
   VAE_CHECK(a.X16 == nullptr || (a.xf == VAE_XF_NONE && wgrad_use_tile_bf16(a) && aligned16(a.X16) && a.g.Cs % 8 == 0),
             "wgrad: X16 needs bf16 mode, xf == NONE and a layer vae_bf16_act_image_ok accepts");
   if (wgrad_use_tile_bf16(a)) {
