@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_library_exports_every_declared_symbol():
-    from vaehip.lib import lib, SIGNATURES, LIB_PATH
+    from vaehip.lib import lib, SIGNATURES, LIB_PATH, EXPECTED_ABI
     hdr = open(os.path.join(ROOT, "include", "vaehip.h")).read()
     declared = set(re.findall(r"\b(vae_[a-z0-9_]+)\s*\(", hdr))
     declared -= {"vae_conv_geom", "vae_igemm_args", "vae_wgrad_args"}
@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(dll, name), f"{name} declared in vaehip.h but not exported"
     assert declared - {"vae_last_error", "vae_abi_version"} == set(SIGNATURES), "python binding table out of sync with the header"
-    assert lib.abi_version() == 2
+    assert lib.abi_version() == EXPECTED_ABI
     assert isinstance(dll.vae_last_error(), bytes)
 
 

@@ -37,6 +37,7 @@ class WgradArgs(C.Structure):
 
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+EXPECTED_ABI = 3  # vae_abi_version() of the library these structures and signatures describe
 
 # name -> argtypes (every function returns int); must list EVERY symbol of include/vaehip.h
 SIGNATURES = {
@@ -92,6 +93,9 @@ class _Lib:
             dll.vae_last_error.restype = C.c_char_p
             dll.vae_last_error.argtypes = []
             dll.vae_abi_version.restype = C.c_int
+            if dll.vae_abi_version() != EXPECTED_ABI:
+                raise VaeHipError(f"{LIB_PATH} has ABI version {dll.vae_abi_version()}, this binding expects {EXPECTED_ABI}: "
+                                  f"rebuild it (python -c 'import __graft_entry__ as g; g.build()')")
             for name, argt in SIGNATURES.items():
                 fn = getattr(dll, name)
                 fn.restype = C.c_int
