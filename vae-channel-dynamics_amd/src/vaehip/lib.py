@@ -89,6 +89,14 @@ class _Lib:
                 raise VaeHipError(
                     f"libvaehip.so not found at {LIB_PATH}; build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                     f"(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+            # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 but loads it lazily.  If this
+            # library were opened first, its libamdhip64 dependency would resolve to the system copy and the process
+            # would end up with two runtimes (kernels launched through the second find "no ROCm-capable device").
+            # Opening torch's copy first makes the dependency resolve to it.
+            import torch
+            bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+            if os.path.exists(bundled):
+                C.CDLL(bundled, mode=C.RTLD_GLOBAL)
             dll = C.CDLL(LIB_PATH)
             dll.vae_last_error.restype = C.c_char_p
             dll.vae_last_error.argtypes = []
