@@ -88,8 +88,14 @@ typedef struct vae_igemm_args {
   const void* Wh;        /* optional (prec == BF16): bf16 image of W, same element layout (vae_pack_bf16); NULL = round W on the fly */
   const void* A16;       /* optional (prec == BF16, xf == NONE, vae_bf16_act_image_ok): bf16 image of the ALREADY TRANSFORMED
                           * operand, same NHWC layout (vae_gn_apply_bf16); the kernel then reads it instead of A */
+  float* gstat;          /* optional (vae_conv_gstat_chunks(a) > 0): GroupNorm statistics of the OUTPUT from the epilogue:  */
+  int32_t gstat_groups;  /* ws[b][chunk][gstat_groups][2] = (sum, sum of squares) per output tile -- the layout
+                          * vae_gn_stats_partial writes, so vae_gn_stats_final finishes it; saves re-reading the output */
 } vae_igemm_args;
 int vae_igemm_rows(const vae_igemm_args* a, void* stream);
+/* number of chunks per image the launch for `a` (with a->gstat_groups set) would write into a->gstat, or 0 when the
+ * kernel serving it has no statistics epilogue (the caller then runs vae_gn_stats_partial on the output)           */
+int vae_conv_gstat_chunks(const vae_igemm_args* a);
 /* 1 when xf != NONE can be fused for this geometry (the GroupNorm scale/shift rows a tile needs are staged in
  * LDS once per workgroup); 0 => the caller materialises XF(x) with vae_gn_apply and passes xf = NONE.
  * Only tiny spatial sizes (H*W < 128 with several batch items per tile) are not fusable.                  */

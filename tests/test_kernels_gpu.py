@@ -501,3 +501,38 @@ def test_bf16_activation_image(cuda, bf16_mode, packed_weights, B, C, H, W, Co):
     F.conv2d(img, wr, None, 1, 1).backward(_r16(dy))
     assert _rel(gw.cpu(), wr.grad) < 3e-5
     assert _rel(gb.cpu(), dy.sum(dim=(0, 2, 3))) < 3e-5
+
+
+@pytest.mark.parametrize("mode", ["no", "bf16"])
+@pytest.mark.parametrize("kind,B,H,W,Ci,Co", [("c3", 2, 8, 32, 128, 128), ("c3", 1, 4, 64, 256, 512), ("c3up", 2, 4, 16, 128, 256)])
+def test_groupnorm_statistics_from_conv_epilogue(cuda, packed_weights, mode, kind, B, H, W, Ci, Co):
+    """the halo-tile conv kernels leave the GroupNorm partial sums of their OUTPUT (bias and residual included); gn_stats
+    on that tensor then only runs the final pass.  Same mean / rstd / scale / shift as the separate pass over the tensor."""
+    from vaehip import ops
+    gen = torch.Generator().manual_seed(23 + Co + H)
+    x = torch.randn(B, Ci, H, W, generator=gen)
+    w = torch.randn(Co, Ci, 3, 3, generator=gen) / math.sqrt(9 * Ci)
+    b = torch.randn(Co, generator=gen)
+    gamma, beta = (1 + 0.3 * torch.randn(Co, generator=gen)).cuda(), (0.2 * torch.randn(Co, generator=gen)).cuda()
+    ho, wo = (2 * H, 2 * W) if kind == "c3up" else (H, W)
+    res = torch.randn(B, Co, ho, wo, generator=gen)
+    wd = _to_dev_ohwi(w)
+    ops.PRECISION = ops.PREC_BF16 if mode == "bf16" else ops.PREC_F32
+    try:
+        if mode == "bf16":
+            packed_weights(wd)
+        y = ops.conv_fwd(_nhwc(x), wd, b.cuda(), kind, res=_nhwc(res), gstat_groups=32)
+        assert getattr(y, "_gstat", None) is not None and y._gstat[1] == 32
+        st_fused = ops.gn_stats(y, gamma, beta)
+        plain = y.clone()                      # a tensor without the attached partial sums: the ordinary two-pass path
+        st_ref = ops.gn_stats(plain, gamma, beta)
+        for a_, b_ in zip(st_fused, st_ref):
+            assert _rel(a_, b_) < 2e-6
+        yr = F.group_norm(_nchw(y), 32, gamma.cpu(), beta.cpu(), 1e-6)
+        got = ops.gn_apply(y, st_fused, ops.XF_AFFINE)
+        assert _rel(_nchw(got), yr) < 2e-5
+        # no epilogue for shapes the tile kernels do not serve: gn_stats falls back silently
+        y2 = ops.conv_fwd(_nhwc(x)[:, :5, :7].contiguous(), wd, b.cuda(), "c3", gstat_groups=32)
+        assert getattr(y2, "_gstat", None) is None
+    finally:
+        ops.PRECISION = ops.PREC_F32

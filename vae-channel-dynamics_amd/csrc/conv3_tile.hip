@@ -205,7 +205,7 @@ __global__ __launch_bounds__(NT) void conv3_tile_kernel(vae_igemm_args p, int ti
   const size_t obytes = (size_t)g.Ho * g.Wo * p.ldc * 4u;
   const auto rsC = VAE_BUF_RSRC(p.C + (int64_t)b * g.Ho * g.Wo * p.ldc, obytes);
   const auto rsR = VAE_BUF_RSRC((p.res ? p.res : p.C) + (int64_t)b * g.Ho * g.Wo * p.ldc, obytes);
-  float tsum[2] = {0.f, 0.f};
+  float tsum[2] = {0.f, 0.f}, gs1[2] = {0.f, 0.f}, gs2[2] = {0.f, 0.f};
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
     const int col = n0 + wn * 64 + ni * 32 + lr;
@@ -228,7 +228,39 @@ __global__ __launch_bounds__(NT) void conv3_tile_kernel(vae_igemm_args p, int ti
       const float v = p.alpha * acc[ni][r] + bv + rv[r];
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, off[r], 0, 0);
       tsum[ni] += (off[r] != BUF_OOB) ? fabsf(v) : 0.f;
+      if (off[r] != BUF_OOB) {
+        gs1[ni] += v;
+        gs2[ni] += v * v;
+      }
     }
+  }
+  if (p.gstat) {  // uniform: GroupNorm partial sums of this tile's outputs (layout of vae_gn_stats_partial)
+    const int cpg = p.N / p.gstat_groups, gpt = BN / cpg;  // channels per group (4, 8 or 16), groups per 128-channel tile
+    float* red2 = smem + 4 * BN;                           // [4 rows][gpt][2], behind the tracker scratch
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      float a1 = gs1[ni], a2 = gs2[ni];
+      for (int o = 1; o < cpg; o <<= 1) {  // the cpg lanes of a group are adjacent
+        a1 += __shfl_xor(a1, o, 64);
+        a2 += __shfl_xor(a2, o, 64);
+      }
+      a1 += __shfl_xor(a1, 32, 64);
+      a2 += __shfl_xor(a2, 32, 64);
+      if (lh == 0 && (lr & (cpg - 1)) == 0) {
+        const int gl = (wn * 64 + ni * 32 + lr) / cpg;
+        red2[(wm * gpt + gl) * 2] = a1;
+        red2[(wm * gpt + gl) * 2 + 1] = a2;
+      }
+    }
+    __syncthreads();
+    if (tid < gpt) {
+      const float s1 = (red2[tid * 2] + red2[(gpt + tid) * 2]) + (red2[(2 * gpt + tid) * 2] + red2[(3 * gpt + tid) * 2]);
+      const float s2 = (red2[tid * 2 + 1] + red2[(gpt + tid) * 2 + 1]) + (red2[(2 * gpt + tid) * 2 + 1] + red2[(3 * gpt + tid) * 2 + 1]);
+      float* o = p.gstat + (((int64_t)b * (tiles_x * tiles_y) + ty * tiles_x + tx) * p.gstat_groups + n0 / cpg + tid) * 2;
+      o[0] = s1;
+      o[1] = s2;
+    }
+    __syncthreads();
   }
   if (p.track) {
     float* red = smem;  // [4][BN]; the loop's last barrier separates this from the MFMA-phase reads
@@ -267,6 +299,15 @@ bool conv3_tile_eligible(const vae_igemm_args& a, bool vec, bool bkm) {
   if (g.mode == VAE_MODE_UP2X) return g.Ho == 2 * g.Hs && g.Wo == 2 * g.Ws && !bkm;
   if (g.mode == VAE_MODE_DGRAD) return g.Ho == g.Hs && g.Wo == g.Ws && bkm && a.xf == VAE_XF_NONE;
   return false;
+}
+
+// chunks per image of the statistics epilogue (0 = not available for these arguments)
+int conv3_tile_gstat_chunks(const vae_igemm_args& a) {
+  const vae_conv_geom& g = a.g;
+  if (a.gstat_groups <= 0 || a.N % BN != 0 || a.N % a.gstat_groups != 0 || g.mode == VAE_MODE_DGRAD) return 0;
+  const int cpg = a.N / a.gstat_groups;
+  if (cpg != 4 && cpg != 8 && cpg != 16) return 0;
+  return (g.Wo / TW) * (g.Ho / TH);
 }
 
 int launch_conv3_tile(const vae_igemm_args& a, bool bkm, hipStream_t st) {

@@ -302,7 +302,7 @@ __global__ __launch_bounds__(NT, 2) void conv3_tile_bf16_kernel(vae_igemm_args p
     const size_t obytes = (size_t)g.Ho * g.Wo * p.ldc * 4u;
     const auto rsC = VAE_BUF_RSRC(p.C + (int64_t)cur.b * g.Ho * g.Wo * p.ldc, obytes);
     const auto rsR = VAE_BUF_RSRC((p.res ? p.res : p.C) + (int64_t)cur.b * g.Ho * g.Wo * p.ldc, obytes);
-    float tsum[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    float tsum[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, gs1[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, gs2[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
       const int oy = cur.y0 + 2 * wm + mi;
@@ -328,9 +328,44 @@ __global__ __launch_bounds__(NT, 2) void conv3_tile_bf16_kernel(vae_igemm_args p
           const float v = p.alpha * acc[mi][ni][r] + bv + rv[r];
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, off[r], 0, 0);
           tsum[mi][ni] += (off[r] != BUF_OOB) ? fabsf(v) : 0.f;
+          if (off[r] != BUF_OOB) {
+            gs1[mi][ni] += v;
+            gs2[mi][ni] += v * v;
+          }
           acc[mi][ni][r] = 0.f;
         }
       }
+    }
+    if (p.gstat) {  // uniform: GroupNorm partial sums of this tile's outputs (layout of vae_gn_stats_partial)
+      const int cpg = p.N / p.gstat_groups, gpt = BN / cpg;  // channels per group (4, 8 or 16), groups per 128-channel tile
+      float* red2 = reinterpret_cast<float*>(smem) + 4 * BN;  // [4 rows][gpt][2] behind the tracker scratch, in the halo stage
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          float a1 = gs1[mi][ni], a2 = gs2[mi][ni];
+          for (int o = 1; o < cpg; o <<= 1) {  // the cpg lanes of a group are adjacent
+            a1 += __shfl_xor(a1, o, 64);
+            a2 += __shfl_xor(a2, o, 64);
+          }
+          a1 += __shfl_xor(a1, 32, 64);
+          a2 += __shfl_xor(a2, 32, 64);
+          if (lh == 0 && (lr & (cpg - 1)) == 0) {
+            const int gl = (wn * 64 + ni * 32 + lr) / cpg;
+            red2[((2 * wm + mi) * gpt + gl) * 2] = a1;
+            red2[((2 * wm + mi) * gpt + gl) * 2 + 1] = a2;
+          }
+        }
+      __syncthreads();
+      if (tid < gpt) {
+        const float s1 = (red2[tid * 2] + red2[(gpt + tid) * 2]) + (red2[(2 * gpt + tid) * 2] + red2[(3 * gpt + tid) * 2]);
+        const float s2 = (red2[tid * 2 + 1] + red2[(gpt + tid) * 2 + 1]) + (red2[(2 * gpt + tid) * 2 + 1] + red2[(3 * gpt + tid) * 2 + 1]);
+        const int tile_in_img = cur.lin - cur.b * (tiles_x * tiles_y);
+        float* o = p.gstat + (((int64_t)cur.b * (tiles_x * tiles_y) + tile_in_img) * p.gstat_groups + cur.n0 / cpg + tid) * 2;
+        o[0] = s1;
+        o[1] = s2;
+      }
+      __syncthreads();
     }
     if (p.track) {  // uniform; the last loop barrier separated the halo reads from this reuse of its space
       float* red = reinterpret_cast<float*>(smem);  // [4 rows][BN] fp32 = 2 KB of the 16 KB halo stage

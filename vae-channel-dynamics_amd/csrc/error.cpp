@@ -13,4 +13,4 @@ void vae_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* vae_last_error(void) { return g_err; }
-extern "C" int vae_abi_version(void) { return 3; }
+extern "C" int vae_abi_version(void) { return 4; }

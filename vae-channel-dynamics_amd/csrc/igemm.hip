@@ -22,6 +22,7 @@ bool conv3_tile_eligible(const vae_igemm_args& a, bool vec, bool bkm);
 int launch_conv3_tile(const vae_igemm_args& a, bool bkm, hipStream_t st);
 int launch_conv3_tile_bf16(const vae_igemm_args& a, bool bkm, hipStream_t st);
 bool conv3_tile_bf16_packed(const vae_igemm_args& a);
+int conv3_tile_gstat_chunks(const vae_igemm_args& a);  // both tile kernels share the tile shape and the epilogue layout
 bool wgrad3_tile_eligible(const vae_wgrad_args& a, bool vec);
 int64_t wgrad3_tile_units(const vae_conv_geom& g);
 int launch_wgrad3_tile(const vae_wgrad_args& a, hipStream_t st);
@@ -685,6 +686,15 @@ extern "C" int vae_bf16_act_image_ok(const vae_conv_geom* gp, int32_t Cout, int3
   return wgrad_use_tile_bf16(w) ? 1 : 0;
 }
 
+extern "C" int vae_conv_gstat_chunks(const vae_igemm_args* ap) {
+  if (!ap) return 0;
+  const vae_igemm_args& a = *ap;
+  const bool bkm = rows_bkm(a), vec = rows_vec(a, bkm);
+  if (a.A16 == nullptr && conv_smallk_eligible(a)) return 0;
+  if (rows_use_tile_bf16(a, vec, bkm) || (a.prec != VAE_PREC_BF16 && rows_use_tile(a, vec, bkm))) return conv3_tile_gstat_chunks(a);
+  return 0;
+}
+
 // name of the kernel instantiation vae_igemm_rows / vae_wgrad dispatch to for these arguments
 // (profiling labels that match the rocprofv3 kernel names; no launch)
 extern "C" int vae_igemm_kernel_name(const vae_igemm_args* ap, char* buf, int32_t n) {
@@ -739,6 +749,7 @@ extern "C" int vae_igemm_rows(const vae_igemm_args* ap, void* stream) {
             "igemm_rows: fused GroupNorm needs the tile's scale/shift rows to fit LDS (see vae_xf_fusable_rows)");
   const bool bkm = rows_bkm(a);
   const bool vec = rows_vec(a, bkm);
+  VAE_CHECK(a.gstat == nullptr || vae_conv_gstat_chunks(ap) > 0, "igemm_rows: no statistics epilogue for these arguments (vae_conv_gstat_chunks)");
   hipStream_t st = (hipStream_t)stream;
   if (a.A16 == nullptr && conv_smallk_eligible(a)) {
     if (int rc2 = launch_conv_smallk(a, st)) return rc2;

@@ -59,14 +59,30 @@ __global__ __launch_bounds__(256) void gn_stats_final_kernel(const float* __rest
                                                              float* __restrict__ mean, float* __restrict__ rstd,
                                                              float* __restrict__ scale, float* __restrict__ shift) {
   __shared__ float smean[64], srstd[64];
+  __shared__ double sS[256], sQ[256];
   const int b = blockIdx.x;
+  // the chunk range is dealt out to 256 / G threads per group (a conv epilogue leaves one chunk per output tile: hundreds),
+  // partial sums in fp64, combined in a fixed order
+  const int parts = 256 / G;  // G <= 64
+  {
+    const int g = threadIdx.x % G, part = threadIdx.x / G;
+    double S = 0.0, Q = 0.0;
+    if (part < parts)
+      for (int c = part; c < nchunk; c += parts) {
+        const float* o = ws + (((int64_t)b * nchunk + c) * G + g) * 2;
+        S += (double)o[0];
+        Q += (double)o[1];
+      }
+    sS[threadIdx.x] = S;
+    sQ[threadIdx.x] = Q;
+  }
+  __syncthreads();
   if (threadIdx.x < G) {
     const int g = threadIdx.x;
     double S = 0.0, Q = 0.0;
-    for (int c = 0; c < nchunk; ++c) {
-      const float* o = ws + (((int64_t)b * nchunk + c) * G + g) * 2;
-      S += (double)o[0];
-      Q += (double)o[1];
+    for (int part = 0; part < parts; ++part) {
+      S += sS[part * G + g];
+      Q += sQ[part * G + g];
     }
     const double n = (double)HW * (double)(C / G);
     const double m = S / n;

@@ -206,7 +206,10 @@ class Engine:
             a16 = ops.gn_apply_bf16(x, st, xf)
             if self._keep16:
                 self._a16[id(m)] = a16
-        y = ops.conv_fwd(x, m.weight, m.bias, kind, xf=xf, stats=st, res=res if fuse_res else None, track=tb, a16=a16)
+        # every 3x3 output of this model feeds a GroupNorm(32) next (or is summed first: then the statistics are dropped)
+        want_stats = ops.GN_GROUPS if (kind in ("c3", "c3up") and (res is None or fuse_res)) else None
+        y = ops.conv_fwd(x, m.weight, m.bias, kind, xf=xf, stats=st, res=res if fuse_res else None, track=tb, a16=a16,
+                         gstat_groups=want_stats)
         if sinks:
             v = ops.track_final(tb, y.shape[0] * y.shape[1] * y.shape[2])
             for s in sinks:

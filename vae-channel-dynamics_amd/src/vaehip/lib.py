@@ -26,7 +26,8 @@ class IgemmArgs(C.Structure):
                 ("track", _fp), ("g", ConvGeom), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
                 ("ldc", C.c_int32), ("sn", C.c_int64), ("sk", C.c_int64), ("st", C.c_int64),
                 ("batch", C.c_int32), ("sAb", C.c_int64), ("sWb", C.c_int64), ("sCb", C.c_int64),
-                ("xf", C.c_int32), ("alpha", C.c_float), ("prec", C.c_int32), ("Wh", _fp), ("A16", _fp)]
+                ("xf", C.c_int32), ("alpha", C.c_float), ("prec", C.c_int32), ("Wh", _fp), ("A16", _fp),
+                ("gstat", _fp), ("gstat_groups", C.c_int32)]
 
 
 class WgradArgs(C.Structure):
@@ -37,11 +38,12 @@ class WgradArgs(C.Structure):
 
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
-EXPECTED_ABI = 3  # vae_abi_version() of the library these structures and signatures describe
+EXPECTED_ABI = 4  # vae_abi_version() of the library these structures and signatures describe
 
 # name -> argtypes (every function returns int); must list EVERY symbol of include/vaehip.h
 SIGNATURES = {
     "vae_igemm_rows": [C.POINTER(IgemmArgs), vp],
+    "vae_conv_gstat_chunks": [C.POINTER(IgemmArgs)],
     "vae_wgrad": [C.POINTER(WgradArgs), vp],
     "vae_xf_fusable_rows": [C.POINTER(ConvGeom), i32, i32],
     "vae_wgrad_plan": [C.POINTER(WgradArgs), C.POINTER(i32), C.POINTER(i32)],

@@ -17,6 +17,9 @@ PREC_F32, PREC_BF16 = 0, 1
 PRECISION = PREC_F32
 
 
+# GroupNorm statistics of a conv output from that conv's epilogue (conv_fwd(gstat_groups=)); False = always re-read the tensor
+FUSED_GN_STATS = True
+
 # bf16 image of a parameter arena (base address of the fp32 arena, its size in bytes, base address of the image):
 # weights that live inside the arena are handed to the bf16 kernels as `Wh` (set by the engine per forward)
 WEIGHTS16: Optional[Tuple[int, int, int]] = None
@@ -186,9 +189,12 @@ def gn_apply_bf16(x: torch.Tensor, st: "Stats", xf: int) -> torch.Tensor:
 
 def conv_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], kind: str, *,
              xf: int = XF_NONE, stats: Optional[Stats] = None, res: Optional[torch.Tensor] = None,
-             track: Optional[torch.Tensor] = None, a16: Optional[torch.Tensor] = None) -> torch.Tensor:
+             track: Optional[torch.Tensor] = None, a16: Optional[torch.Tensor] = None,
+             gstat_groups: Optional[int] = None) -> torch.Tensor:
     """x [B,H,W,Cs] (Cs >= Cin, extra channels must be zero-weighted i.e. Cin is taken from w).
-    a16: bf16 image of XF(x) (then xf / stats are not applied again; x only gives the geometry)."""
+    a16: bf16 image of XF(x) (then xf / stats are not applied again; x only gives the geometry).
+    gstat_groups: the output feeds a GroupNorm with that many groups: where the kernel has a statistics epilogue the
+    partial sums are attached to the returned tensor (`_gstat`) and gn_stats() on it skips its pass over the tensor."""
     _chk_c(x, "conv_fwd.x")
     if a16 is not None:
         assert a16.shape == x.shape and a16.dtype == torch.bfloat16 and a16.is_contiguous()
@@ -218,6 +224,13 @@ def conv_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], kin
     a.xf, a.alpha, a.prec, a.Wh, a.A16 = xf, 1.0, PRECISION, _wh(wv), _p(a16)
     if track is not None:
         assert track.numel() >= ((a.M + 127) // 128) * Co
+    if gstat_groups and FUSED_GN_STATS:
+        a.gstat_groups = int(gstat_groups)
+        nch = lib.query("vae_conv_gstat_chunks", C.byref(a))
+        if nch > 0:
+            ws = torch.empty((B, nch, int(gstat_groups), 2), device=x.device, dtype=torch.float32)
+            a.gstat = _p(ws)
+            out._gstat = (ws, int(gstat_groups), nch)
     _launch_igemm(a)
     return out
 
@@ -323,14 +336,18 @@ def gn_stats(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, G: int = 
     _chk_c(x, "gn_stats.x")
     B, H, W, Cc = x.shape
     HW = H * W
-    nch = _gn_nchunk(B, HW, Cc)
     dev = x.device
-    ws = torch.empty((B, nch, G, 2), device=dev, dtype=torch.float32)
+    fused = getattr(x, "_gstat", None)  # partial sums left by the conv epilogue that produced x (conv_fwd(gstat_groups=G))
+    if fused is not None and fused[1] == G and FUSED_GN_STATS:
+        ws, nch = fused[0], fused[2]
+    else:
+        nch = _gn_nchunk(B, HW, Cc)
+        ws = torch.empty((B, nch, G, 2), device=dev, dtype=torch.float32)
+        lib.call("vae_gn_stats_partial", _p(x), B, HW, Cc, G, nch, _p(ws), _stream())
     mean = torch.empty((B, G), device=dev, dtype=torch.float32)
     rstd = torch.empty((B, G), device=dev, dtype=torch.float32)
     scale = torch.empty((B, Cc), device=dev, dtype=torch.float32)
     shift = torch.empty((B, Cc), device=dev, dtype=torch.float32)
-    lib.call("vae_gn_stats_partial", _p(x), B, HW, Cc, G, nch, _p(ws), _stream())
     lib.call("vae_gn_stats_final", _p(ws), B, HW, Cc, G, nch, _p(gamma), _p(beta), eps, _p(mean), _p(rstd),
              _p(scale), _p(shift), _stream())
     return Stats(mean, rstd, scale, shift)
