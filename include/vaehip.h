@@ -33,6 +33,8 @@ extern "C" {
 
 const char* vae_last_error(void);
 int vae_abi_version(void);
+/* sizeof(vae_conv_geom / vae_igemm_args / vae_wgrad_args) for which = 0 / 1 / 2: lets a binding verify its struct mirrors */
+int vae_sizeof_args(int32_t which);
 
 /* input transform applied to the A operand while it is staged into LDS */
 #define VAE_XF_NONE 0

@@ -18,7 +18,10 @@ def test_library_exports_every_declared_symbol():
     dll = lib.load()
     for name in sorted(declared):
         assert hasattr(dll, name), f"{name} declared in vaehip.h but not exported"
-    assert declared - {"vae_last_error", "vae_abi_version"} == set(SIGNATURES), "python binding table out of sync with the header"
+    assert declared - {"vae_last_error", "vae_abi_version", "vae_sizeof_args"} == set(SIGNATURES), "python binding table out of sync with the header"
+    from vaehip.lib import ConvGeom, IgemmArgs, WgradArgs
+    import ctypes as C
+    assert [dll.vae_sizeof_args(i) for i in range(3)] == [C.sizeof(ConvGeom), C.sizeof(IgemmArgs), C.sizeof(WgradArgs)]
     assert lib.abi_version() == EXPECTED_ABI
     assert isinstance(dll.vae_last_error(), bytes)
 

@@ -106,6 +106,12 @@ class _Lib:
             if dll.vae_abi_version() != EXPECTED_ABI:
                 raise VaeHipError(f"{LIB_PATH} has ABI version {dll.vae_abi_version()}, this binding expects {EXPECTED_ABI}: "
                                   f"rebuild it (python -c 'import __graft_entry__ as g; g.build()')")
+            dll.vae_sizeof_args.restype = C.c_int
+            dll.vae_sizeof_args.argtypes = [C.c_int32]
+            for which, mirror in enumerate((ConvGeom, IgemmArgs, WgradArgs)):
+                if dll.vae_sizeof_args(which) != C.sizeof(mirror):
+                    raise VaeHipError(f"{mirror.__name__}: ctypes mirror is {C.sizeof(mirror)} bytes, the library's struct "
+                                      f"{dll.vae_sizeof_args(which)} -- lib.py and include/vaehip.h are out of sync")
             for name, argt in SIGNATURES.items():
                 fn = getattr(dll, name)
                 fn.restype = C.c_int
