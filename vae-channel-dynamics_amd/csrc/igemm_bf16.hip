@@ -170,8 +170,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_rows_bf16_kernel(vae_igemm
       for (int i = 0; i < BR; ++i) *reinterpret_cast<uint2*>(&sB[(kq + KR * i) * LDB + n4 * 4]) = pack4(rw[i]);
     }
   };
-  auto compute = [&](const u16* sA, const u16* sB, int kg) {
-    bf16x8 a[MI], b[NI];
+  // fragments of k-group kg+1 are requested before the MFMAs of kg (pinned with sched_barrier; see conv3_tile_bf16.hip)
+  bf16x8 fa[2][MI], fb[2][NI];
+  auto fetch = [&](const u16* sA, const u16* sB, int kg, bf16x8* a, bf16x8* b) {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) a[mi] = frag_direct(sA + (wm * TM + mi * 32 + lr) * LDA + kg * 16 + lh * 8);
 #pragma unroll
@@ -179,10 +180,16 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_rows_bf16_kernel(vae_igemm
       if (!BKM) b[ni] = frag_direct(sB + (wn * TN + ni * 32 + lr) * LDB + kg * 16 + lh * 8);
       else b[ni] = frag_tr(sB + (kg * 16 + lh * 8 + trq) * LDB + wn * TN + ni * 32 + trh * 16 + trp * 4, LDB);
     }
+  };
+  auto compute = [&](const u16* sA, const u16* sB, int kg) {  // fragments of kg already requested
+    if (kg + 1 < BK / 16) fetch(sA, sB, kg + 1, fa[(kg + 1) & 1], fb[(kg + 1) & 1]);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+      for (int ni = 0; ni < NI; ++ni)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kg & 1][mi], fb[kg & 1][ni], acc[mi][ni], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
   };
 
   load_regs(0);
@@ -193,6 +200,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_rows_bf16_kernel(vae_igemm
   for (int s = 0; s < steps; ++s) {
     const u16* cA = smem + (s & 1) * STAGE;
     const u16* cB = cA + SA;
+    fetch(cA, cB, 0, fa[0], fb[0]);
     compute(cA, cB, 0);
     compute(cA, cB, 1);
     if (s + 1 < steps) {
@@ -372,16 +380,22 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_bf16_kernel(vae_wgrad_args
       *reinterpret_cast<uint2*>(&sB[(bkq + BKR * i) * LDB + b4 * 4]) = pack4(v);
     }
   };
-  auto compute = [&](const u16* sA, const u16* sB, int kg) {
-    bf16x8 a[MI], b[NI];
+  bf16x8 fa[2][MI], fb[2][NI];
+  auto fetch = [&](const u16* sA, const u16* sB, int kg, bf16x8* a, bf16x8* b) {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) a[mi] = frag_tr(sA + (kg * 16 + lh * 8 + trq) * LDA + wm * TM + mi * 32 + trh * 16 + trp * 4, LDA);
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) b[ni] = frag_tr(sB + (kg * 16 + lh * 8 + trq) * LDB + wn * TN + ni * 32 + trh * 16 + trp * 4, LDB);
+  };
+  auto compute = [&](const u16* sA, const u16* sB, int kg) {  // fragments of kg already requested
+    if (kg + 1 < BK / 16) fetch(sA, sB, kg + 1, fa[(kg + 1) & 1], fb[(kg + 1) & 1]);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+      for (int ni = 0; ni < NI; ++ni)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kg & 1][mi], fb[kg & 1][ni], acc[mi][ni], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
   };
 
   if (steps > 0) {
@@ -393,6 +407,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_bf16_kernel(vae_wgrad_args
     for (int s = 0; s < steps; ++s) {
       const u16* cA = smem + (s & 1) * STAGE;
       const u16* cB = cA + SA;
+      fetch(cA, cB, 0, fa[0], fb[0]);
       compute(cA, cB, 0);
       if (s + 1 < steps) {
         u16* nA = smem + ((s + 1) & 1) * STAGE;
