@@ -81,40 +81,16 @@ __device__ __forceinline__ float wave_sum(float v) {
 // ---------------------------------------------------------------------------------------
 constexpr int SS_HALF = 512;  // floats of GroupNorm scale (and of shift) kept in LDS per workgroup
 
-template <bool VEC>
-__device__ __forceinline__ f32x4 load4(const float* p, int c, int C) {
+// Unvectorised guarded load (channel counts that are not a multiple of 4, unaligned rows): element by element.  The
+// vectorised paths use the buffer-descriptor loads below instead.
+__device__ __forceinline__ f32x4 load4s(const float* p, bool ok, int c, int C) {
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  if (VEC) {
-    if (c < C) v = *reinterpret_cast<const f32x4*>(p);
-  } else {
+  if (ok) {
 #pragma unroll
     for (int e = 0; e < 4; ++e)
       if (c + e < C) v[e] = p[e];
   }
   return v;
-}
-
-// Branch-free guarded load: an invalid lane reads the (always mapped, 16-B aligned) `safe` address and the
-// value is zeroed afterwards.  A per-lane `if (ok) load` makes hipcc wrap every load in an exec-mask branch
-// and wait for it separately (cdna_hip_programming.md, "Three .s-level traps" (c)).
-template <bool VEC>
-__device__ __forceinline__ f32x4 load4g(const float* p, bool ok, const float* safe, int c, int C) {
-  if (VEC) {
-    ok = ok && (c < C);
-    const float* q = ok ? p : safe;
-    f32x4 v = *reinterpret_cast<const f32x4*>(q);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
-    return v;
-  } else {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (ok) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (c + e < C) v[e] = p[e];
-    }
-    return v;
-  }
 }
 
 // Buffer-descriptor loads.  The descriptor covers [base, base + bytes) with a 32-bit per-lane byte offset; an offset

@@ -7,8 +7,8 @@
 //     - weight tile n-contiguous : conv/linear dgrad, P.V, dS.K
 //   wgrad  (contraction over pixels; both tiles k-major) : conv/linear wgrad, P^T.dO, dS^T.Q
 //
-// Tiling: 256 threads = 4 waves, BK = 32, wave tile = (BM/WM) x (BN/WN) built from
-// 32x32 MFMA tiles.  LDS tiles are padded so every ds_read_b128 fragment read is
+// Tiling: 64*WM*WN threads (8 waves for the 128x128 tile, 4 for the skinny ones), BK = 32, wave tile =
+// (BM/WM) x (BN/WN) built from 32x32 MFMA tiles.  LDS tiles are padded so every ds_read_b128 fragment read is
 // bank-conflict free (row stride 36 dwords: 36*i mod 64 hits 16 distinct 16-B slots
 // for the 16 rows of a b128 lane group).  Global loads of step s+1 are issued before
 // the MFMA block of step s and written to LDS after it (register-staged prefetch);
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_rows_kernel(vae_igemm_args
       if (VEC) {
         ra[i] = VAE_BUF_LOAD4(rsA, (ok && c < p.K) ? ((unsigned)(((rb[i] - b_base) * g.Hs + sy) * g.Ws + sx) * (unsigned)g.Cs + (unsigned)c) * 4u : BUF_OOB);
       } else {
-        ra[i] = load4g<false>(A + (((int64_t)rb[i] * g.Hs + sy) * g.Ws + sx) * g.Cs + c, ok, A, c, p.K);
+        ra[i] = load4s(A + (((int64_t)rb[i] * g.Hs + sy) * g.Ws + sx) * g.Cs + c, ok, c, p.K);
       }
       a_b[i] = ok ? rb[i] : -1;
     }
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_rows_kernel(vae_igemm_args
       for (int i = 0; i < BR; ++i) {
         const int n = n0 + r0 + RP * i;
         if (VEC) rbw[i] = VAE_BUF_LOAD4(rsW, (n < p.N && c < p.K) ? ((unsigned)n * (unsigned)p.sn + (unsigned)tap * (unsigned)p.st + (unsigned)c) * 4u : BUF_OOB);
-        else rbw[i] = load4g<false>(W + (int64_t)n * p.sn + (int64_t)tap * p.st + c, n < p.N, W, c, p.K);
+        else rbw[i] = load4s(W + (int64_t)n * p.sn + (int64_t)tap * p.st + c, n < p.N, c, p.K);
       }
     } else {
       constexpr int NQ = BN / 4, KR = NL / NQ;
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_rows_kernel(vae_igemm_args
         const int k = c0 + kq + KR * i;
         const int n = n0 + n4 * 4;
         if (VEC) rbw[i] = VAE_BUF_LOAD4(rsW, (k < p.K && n < p.N) ? ((unsigned)k * (unsigned)p.sk + (unsigned)tap * (unsigned)p.st + (unsigned)n) * 4u : BUF_OOB);
-        else rbw[i] = load4g<false>(W + (int64_t)k * p.sk + (int64_t)tap * p.st + n, k < p.K, W, n, p.N);
+        else rbw[i] = load4s(W + (int64_t)k * p.sk + (int64_t)tap * p.st + n, k < p.K, n, p.N);
       }
     }
   };
@@ -225,8 +225,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_rows_kernel(vae_igemm_args
   };
 
   const int lr = lane & 31, lh = lane >> 5;
-  auto compute = [&](const float* sA, const float* sB, int kk) {
-    f32x4 a[MI], b[NI];
+  // fragments of k-group kk+1 are requested before the MFMAs of kk are issued (pinned with sched_barrier)
+  f32x4 fa[2][MI], fb[2][NI];
+  auto fetch = [&](const float* sA, const float* sB, int kk, f32x4* a, f32x4* b) {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
       a[mi] = *reinterpret_cast<const f32x4*>(&sA[(wm * TM + mi * 32 + lr) * LDA + kk * 8 + lh * 4]);
@@ -239,6 +240,10 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_rows_kernel(vae_igemm_args
         for (int j = 0; j < 4; ++j) b[ni][j] = sB[(kk * 8 + lh * 4 + j) * LDB + wn * TN + ni * 32 + lr];
       }
     }
+  };
+  auto compute = [&](const float* sA, const float* sB, int kk) {  // fragments of kk already requested
+    if (kk + 1 < BK / 8) fetch(sA, sB, kk + 1, fa[(kk + 1) & 1], fb[(kk + 1) & 1]);
+    __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -246,8 +251,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_rows_kernel(vae_igemm_args
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][mi][j], fb[kk & 1][ni][j], acc[mi][ni], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
   };
 
   load_regs(0);
@@ -258,6 +264,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_rows_kernel(vae_igemm_args
   for (int s = 0; s < steps; ++s) {
     const float* cA = smem + (s & 1) * STAGE;
     const float* cB = cA + SA;
+    fetch(cA, cB, 0, fa[0], fb[0]);
     compute(cA, cB, 0);
     compute(cA, cB, 1);
     if (s + 1 < steps) {  // staged in the shadow of the MFMAs already issued
@@ -412,7 +419,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(vae_wgrad_args p) {
       const int pix = pb + akq + AKR * i;
       const int c = m0 + a4 * 4;
       if (VEC) ra[i] = VAE_BUF_LOAD4(rsY, (pix < pend && c < p.M) ? ((unsigned)(pix - pbeg) * (unsigned)p.ldy + (unsigned)c) * 4u : BUF_OOB);
-      else ra[i] = load4g<false>(dY + (int64_t)pix * p.ldy + c, pix < pend, dY, c, p.M);
+      else ra[i] = load4s(dY + (int64_t)pix * p.ldy + c, pix < pend, c, p.M);
     }
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
@@ -423,7 +430,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(vae_wgrad_args p) {
       int sy = 0, sx = 0;
       const bool ok = src_pixel(g, y, x, kh, kw, sy, sx) && (pix < pend);
       if (VEC) rx[i] = VAE_BUF_LOAD4(rsX, (ok && c < p.N) ? ((unsigned)(((b - b_lo) * g.Hs + sy) * g.Ws + sx) * (unsigned)g.Cs + (unsigned)c) * 4u : BUF_OOB);
-      else rx[i] = load4g<false>(X + (((int64_t)b * g.Hs + sy) * g.Ws + sx) * g.Cs + c, ok, X, c, p.N);
+      else rx[i] = load4s(X + (((int64_t)b * g.Hs + sy) * g.Ws + sx) * g.Cs + c, ok, c, p.N);
       xb[i] = ok ? b : -1;
     }
   };
@@ -446,8 +453,8 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(vae_wgrad_args p) {
   };
 
   const int lr = lane & 31, lh = lane >> 5;
-  auto compute = [&](const float* sA, const float* sB, int kk) {
-    f32x4 a[MI], b[NI];
+  f32x4 fa[2][MI], fb[2][NI];
+  auto fetch = [&](const float* sA, const float* sB, int kk, f32x4* a, f32x4* b) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int k = kk * 8 + lh * 4 + j;
@@ -456,6 +463,10 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(vae_wgrad_args p) {
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) b[ni][j] = sB[k * LDB + wn * TN + ni * 32 + lr];
     }
+  };
+  auto compute = [&](const float* sA, const float* sB, int kk) {  // fragments of kk already requested
+    if (kk + 1 < BK / 8) fetch(sA, sB, kk + 1, fa[(kk + 1) & 1], fb[(kk + 1) & 1]);
+    __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -463,8 +474,9 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(vae_wgrad_args p) {
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][mi][j], fb[kk & 1][ni][j], acc[mi][ni], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
   };
 
   if (steps > 0) {
@@ -476,6 +488,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(vae_wgrad_args p) {
     for (int s = 0; s < steps; ++s) {
       const float* cA = smem + (s & 1) * STAGE;
       const float* cB = cA + SA;
+      fetch(cA, cB, 0, fa[0], fb[0]);
       compute(cA, cB, 0);
       compute(cA, cB, 1);
       if (s + 1 < steps) {
