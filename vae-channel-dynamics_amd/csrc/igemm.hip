@@ -32,6 +32,8 @@ int wgrad3_tile_bf16_columns(const vae_wgrad_args& a);
 int launch_wgrad3_tile_bf16(const vae_wgrad_args& a, hipStream_t st);
 bool conv_smallk_eligible(const vae_igemm_args& a);                      // skinny.hip (<= 4-channel sides on the VALU)
 int launch_conv_smallk(const vae_igemm_args& a, hipStream_t st);
+bool conv_smalln_eligible(const vae_igemm_args& a);
+int launch_conv_smalln(const vae_igemm_args& a, hipStream_t st);
 int wgrad_smallk_kind(const vae_wgrad_args& a);
 int wgrad_smallk_tiles(const vae_wgrad_args& a);
 int launch_wgrad_smallk(const vae_wgrad_args& a, hipStream_t st);
@@ -703,7 +705,7 @@ extern "C" int vae_conv_gstat_chunks(const vae_igemm_args* ap) {
   if (!ap) return 0;
   const vae_igemm_args& a = *ap;
   const bool bkm = rows_bkm(a), vec = rows_vec(a, bkm);
-  if (a.A16 == nullptr && conv_smallk_eligible(a)) return 0;
+  if ((a.A16 == nullptr && conv_smallk_eligible(a)) || conv_smalln_eligible(a)) return 0;
   if (rows_use_tile_bf16(a, vec, bkm) || (a.prec != VAE_PREC_BF16 && rows_use_tile(a, vec, bkm))) return conv3_tile_gstat_chunks(a);
   return 0;
 }
@@ -717,6 +719,8 @@ extern "C" int vae_igemm_kernel_name(const vae_igemm_args* ap, char* buf, int32_
   const char* tf[2] = {"false", "true"};
   if (conv_smallk_eligible(a))
     snprintf(buf, n, "conv_smallk_kernel");
+  else if (conv_smalln_eligible(a))
+    snprintf(buf, n, "conv_smalln_kernel<%d>", a.xf);
   else if (rows_use_tile_bf16(a, vec, bkm))
     snprintf(buf, n, "conv3_tile_bf16_kernel<%s,%s,%d,%s>", tf[a.g.mode == VAE_MODE_DGRAD], tf[a.g.mode == VAE_MODE_UP2X], a.xf,
              tf[a.A16 != nullptr]);
@@ -767,6 +771,11 @@ extern "C" int vae_igemm_rows(const vae_igemm_args* ap, void* stream) {
   if (a.A16 == nullptr && conv_smallk_eligible(a)) {
     if (int rc2 = launch_conv_smallk(a, st)) return rc2;
     VAE_LAUNCH_CHECK("conv_smallk");
+    return VAE_OK;
+  }
+  if (conv_smalln_eligible(a)) {
+    if (int rc2 = launch_conv_smalln(a, st)) return rc2;
+    VAE_LAUNCH_CHECK("conv_smalln");
     return VAE_OK;
   }
   VAE_CHECK(a.A16 == nullptr || (a.xf == VAE_XF_NONE && rows_use_tile_bf16(a, vec, bkm) && aligned16(a.A16) && a.g.Cs % 8 == 0),

@@ -7,6 +7,7 @@
 // accesses are 512-byte rows per pixel; every load goes through a buffer descriptor (out of range = 0).
 //   conv_smallk : y[px][n]      = bias[n] + sum_{tap,s} S[src(px,tap)][s] * W[n][tap][s]      (rows form, K <= 4)
 //   wgrad_smallk: out[..]       = sum_px V[px][lane] * S[src(px,tap)][s]                      (N <= 4 or M <= 4)
+//   conv_smalln : y[px][s]      = bias[s] + sum_{tap,c} XF(x)[px+tap][c] * W[s][tap][c]       (<= 4 outputs; end of file)
 #include "common.h"
 #include <algorithm>
 
@@ -234,5 +235,136 @@ int launch_wgrad_smallk(const vae_wgrad_args& a, hipStream_t st) {
   else if (a.xf == VAE_XF_AFFINE) WSK(false, VAE_XF_AFFINE);
   else WSK(false, VAE_XF_AFFINE_SILU);
 #undef WSK
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// conv_smalln: 3x3 stride-1 'same' convolution with <= 4 OUTPUT channels (decoder.conv_out: 128 -> 3), optionally
+// with GroupNorm(+SiLU) fused on the input.  One lane owns one output pixel of a 4x32-pixel tile and walks the
+// 9 x C input values of its window: activations come from an LDS halo (the staging applies the transform once per
+// halo element), weights are wave-uniform and are read through the scalar cache into SGPRs (v_fma with an SGPR
+// operand), so the VALU does nothing but the 9*C*N useful FMAs per pixel.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int NTH = 4, NTW = 32, NHW = NTW + 2, NHP = (NTH + 2) * NHW;  // 4x32 tile, 204 halo pixels
+constexpr int NBK = 32, NLD = NBK + 4, NNT = 128;
+constexpr int NHQ = NHP * (NBK / 4), NHI = (NHQ + NNT - 1) / NNT;       // 1632 float4 slots, 13 per thread
+
+template <int XF>
+__global__ __launch_bounds__(NNT) void conv_smalln_kernel(vae_igemm_args p, int tiles_x, int tiles_y) {
+  __shared__ __attribute__((aligned(16))) float sH[NHP * NLD];
+  const vae_conv_geom g = p.g;
+  const int tid = threadIdx.x;
+  int t = blockIdx.x;
+  const int tx = t % tiles_x; t /= tiles_x;
+  const int ty = t % tiles_y;
+  const int b = t / tiles_y;
+  const int y0 = ty * NTH, x0 = tx * NTW;
+  const int pr = tid >> 5, px = tid & 31;  // this lane's pixel of the tile
+  const auto rsA = VAE_BUF_RSRC(p.A + (int64_t)b * g.Hs * g.Ws * g.Cs, (size_t)g.Hs * g.Ws * g.Cs * 4u);
+  const float* __restrict__ W = p.W;
+
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const int hk4 = tid & 7;  // the thread's 4 channels are the same for all of its halo slots
+  f32x4 rh[NHI];
+  int hmask = 0;
+  f32x4 rsc = {0.f, 0.f, 0.f, 0.f}, rsh = {0.f, 0.f, 0.f, 0.f};
+  auto load_halo = [&](int c0) {
+    hmask = 0;
+    const int c = c0 + hk4 * 4;
+    if (XF != VAE_XF_NONE) {
+      const int cs = min(c, p.K - 4);
+      rsc = *reinterpret_cast<const f32x4*>(p.scale + (int64_t)b * g.Cs + cs);
+      rsh = *reinterpret_cast<const f32x4*>(p.shift + (int64_t)b * g.Cs + cs);
+    }
+#pragma unroll
+    for (int i = 0; i < NHI; ++i) {
+      const int q = tid + NNT * i;
+      const int pp = q >> 3;
+      const int ir = pp / NHW, jc = pp - ir * NHW;
+      const int hy = y0 - 1 + ir, hx = x0 - 1 + jc;
+      const bool ok = (q < NHQ) && ((unsigned)hy < (unsigned)g.Hs) && ((unsigned)hx < (unsigned)g.Ws) && (c < p.K);
+      rh[i] = VAE_BUF_LOAD4(rsA, ok ? (unsigned)(((hy * g.Ws + hx) * g.Cs + c) * 4) : BUF_OOB);
+      hmask |= (ok ? 1 : 0) << i;
+    }
+  };
+  auto store_halo = [&]() {
+#pragma unroll
+    for (int i = 0; i < NHI; ++i) {
+      const int q = tid + NNT * i;
+      if (q < NHQ) {
+        f32x4 v = rh[i];
+        if (XF != VAE_XF_NONE) {  // padding must stay zero after the transform
+          const bool ok = (hmask >> i) & 1;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float u = v[e] * rsc[e] + rsh[e];
+            if (XF == VAE_XF_AFFINE_SILU) u = silu_f(u);
+            v[e] = ok ? u : 0.f;
+          }
+        }
+        *reinterpret_cast<f32x4*>(&sH[(q >> 3) * NLD + hk4 * 4]) = v;
+      }
+    }
+  };
+
+  const int kchunks = (p.K + NBK - 1) / NBK;
+  load_halo(0);
+  for (int cch = 0; cch < kchunks; ++cch) {
+    const int c0 = cch * NBK;
+    __syncthreads();  // every lane has left the previous chunk's halo
+    store_halo();
+    __syncthreads();
+    if (cch + 1 < kchunks) load_halo(c0 + NBK);  // in flight during this chunk's FMAs
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int kh = tap / 3, kw = tap - kh * 3;
+      const float* hrow = &sH[((pr + kh) * NHW + px + kw) * NLD];
+#pragma unroll
+      for (int q = 0; q < NBK / 4; ++q) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(hrow + q * 4);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          if (s < p.N) {  // uniform
+            // wave-uniform address: the compiler reads these through the scalar cache
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(W + (int64_t)s * p.sn + (int64_t)tap * p.st + c0 + q * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[s] = __builtin_fmaf(a[e], w4[e], acc[s]);
+          }
+        }
+      }
+    }
+  }
+
+  const int oy = y0 + pr, ox = x0 + px;
+  const auto rsC = VAE_BUF_RSRC(p.C + (int64_t)b * g.Ho * g.Wo * p.ldc, (size_t)g.Ho * g.Wo * p.ldc * 4u);
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+    if (s < p.N) {
+      const float v = acc[s] + (p.bias ? p.bias[s] : 0.f);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC,
+                                            (oy < g.Ho && ox < g.Wo) ? (unsigned)(((oy * g.Wo + ox) * p.ldc + s) * 4) : BUF_OOB, 0, 0);
+    }
+}
+
+}  // namespace
+
+bool conv_smalln_eligible(const vae_igemm_args& a) {
+  const vae_conv_geom& g = a.g;
+  return a.N <= 4 && a.K >= NBK && a.K % NBK == 0 && a.sn % 4 == 0 && a.st % 4 == 0 && aligned16(a.W) && a.batch == 1 && a.res == nullptr && a.track == nullptr && a.alpha == 1.0f &&
+         a.A16 == nullptr && g.mode == VAE_MODE_FWD && g.taps == 9 && g.stride == 1 && g.pad_t == 1 && g.pad_l == 1 &&
+         g.Ho == g.Hs && g.Wo == g.Ws && g.Wo % NTW == 0 && g.Ho % NTH == 0 && a.sk == 1 && g.Cs % 4 == 0 && aligned16(a.A) &&
+         (a.xf == VAE_XF_NONE || (aligned16(a.scale) && aligned16(a.shift))) &&
+         (size_t)g.Hs * g.Ws * g.Cs * 4u < BUF_MAX && (size_t)g.Ho * g.Wo * a.ldc * 4u < BUF_MAX && !getenv("VAEHIP_NO_SKINNY");
+}
+int launch_conv_smalln(const vae_igemm_args& a, hipStream_t st) {
+  const int tx = a.g.Wo / NTW, ty = a.g.Ho / NTH;
+  dim3 grid((unsigned)((int64_t)tx * ty * a.g.B));
+  switch (a.xf) {
+    case VAE_XF_NONE: hipLaunchKernelGGL((conv_smalln_kernel<VAE_XF_NONE>), grid, dim3(NNT), 0, st, a, tx, ty); break;
+    case VAE_XF_AFFINE: hipLaunchKernelGGL((conv_smalln_kernel<VAE_XF_AFFINE>), grid, dim3(NNT), 0, st, a, tx, ty); break;
+    default: hipLaunchKernelGGL((conv_smalln_kernel<VAE_XF_AFFINE_SILU>), grid, dim3(NNT), 0, st, a, tx, ty); break;
+  }
   return 0;
 }
