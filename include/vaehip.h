@@ -90,6 +90,14 @@ typedef struct vae_igemm_args {
   const void* Wh;        /* optional (prec == BF16): bf16 image of W, same element layout (vae_pack_bf16); NULL = round W on the fly */
   const void* A16;       /* optional (prec == BF16, xf == NONE, vae_bf16_act_image_ok): bf16 image of the ALREADY TRANSFORMED
                           * operand, same NHWC layout (vae_gn_apply_bf16); the kernel then reads it instead of A */
+  /* Sub-sampled views and tap subsets (vae_conv_phase_ok(a) != 0; zero-initialised = plain): the conv runs on the row grid
+   * of `g`, but pixel (y,x) of A lives at (y*a_step + a_oy, x*a_step + a_ox) of a tensor a_step times larger in H and W,
+   * likewise for C / res with c_step, c_oy, c_ox; only the taps set in tapmask (bit kh*3+kw; 0 = all 9) are computed.
+   * Used for conv-over-nearest-2x-upsample as 4 phase convolutions with 2x2 effective kernels (vae_upconv_phase_weights):
+   * 16 instead of 36 tap-MACs per low-resolution pixel, forward and dgrad.                                             */
+  int32_t tapmask;
+  int32_t a_step, a_oy, a_ox;
+  int32_t c_step, c_oy, c_ox;
   float* gstat;          /* optional (vae_conv_gstat_chunks(a) > 0): GroupNorm statistics of the OUTPUT from the epilogue:  */
   int32_t gstat_groups;  /* ws[b][chunk][gstat_groups][2] = (sum, sum of squares) per output tile -- the layout
                           * vae_gn_stats_partial writes, so vae_gn_stats_final finishes it; saves re-reading the output */
@@ -98,6 +106,12 @@ int vae_igemm_rows(const vae_igemm_args* a, void* stream);
 /* number of chunks per image the launch for `a` (with a->gstat_groups set) would write into a->gstat, or 0 when the
  * kernel serving it has no statistics epilogue (the caller then runs vae_gn_stats_partial on the output)           */
 int vae_conv_gstat_chunks(const vae_igemm_args* a);
+/* 1 when the kernel that would serve `a` honours tapmask / a_step.. / c_step.. (the fp32 halo-tile kernel), else 0  */
+int vae_conv_phase_ok(const vae_igemm_args* a);
+/* W [Co][3][3][Ci] (OHWI) -> Weff [4 phases (a*2+b)][Co][3][3][Ci]: the 3x3 kernel each output parity (a,b) of
+ * conv3x3(nearest_upsample_2x(x)) applies to the LOW-resolution x (zeros outside its 2x2 support; sums of 1, 2 or 4
+ * original taps inside).  tapmask of phase (a,b): rows {0,1} (a=0) or {1,2} (a=1), columns likewise.               */
+int vae_upconv_phase_weights(const float* W, int32_t Co, int32_t Ci, float* Weff, void* stream);
 /* 1 when xf != NONE can be fused for this geometry (the GroupNorm scale/shift rows a tile needs are staged in
  * LDS once per workgroup); 0 => the caller materialises XF(x) with vae_gn_apply and passes xf = NONE.
  * Only tiny spatial sizes (H*W < 128 with several batch items per tile) are not fusable.                  */

@@ -65,6 +65,9 @@ CONV_CASES = [
     ("c3", 2, 12, 32, 512, 256),
     ("c3up", 2, 4, 16, 128, 256),
     ("c3up", 1, 6, 32, 256, 256),
+    # low-resolution W % 32 == 0 and H % 4 == 0: four phase convolutions with 2x2 effective kernels (forward and dgrad)
+    ("c3up", 2, 4, 32, 128, 256),
+    ("c3up", 1, 8, 64, 256, 128),
 ]
 
 
@@ -536,3 +539,36 @@ def test_groupnorm_statistics_from_conv_epilogue(cuda, packed_weights, mode, kin
         assert getattr(y2, "_gstat", None) is None
     finally:
         ops.PRECISION = ops.PREC_F32
+
+
+def test_upconv_phase_decomposition(cuda):
+    """conv3x3(nearest_upsample_2x(x)) == four phase convolutions on x with the effective kernels of
+    vae_upconv_phase_weights: checks the effective kernels themselves and that the phase path is the one that runs."""
+    from vaehip import ops
+    gen = torch.Generator().manual_seed(77)
+    B, H, W, Ci, Co = 2, 4, 32, 128, 128
+    x = torch.randn(B, Ci, H, W, generator=gen)
+    w = torch.randn(Co, Ci, 3, 3, generator=gen) / math.sqrt(9 * Ci)
+    we = ops.upconv_phase_weights(_to_dev_ohwi(w).permute(0, 2, 3, 1)).cpu()      # [4, Co, 3, 3, Ci]
+    y_ref = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, None, 1, 1)
+    for pa in (0, 1):
+        for pb in (0, 1):
+            wp = we[pa * 2 + pb].permute(0, 3, 1, 2)                                 # OIHW
+            mask = torch.zeros(3, 3)
+            for kh in ops._PHASE_MASK[pa]:
+                for kw in ops._PHASE_MASK[pb]:
+                    mask[kh, kw] = 1
+            assert float((wp * (1 - mask)).abs().max()) == 0.0                        # zero outside the 2x2 support
+            assert _rel(F.conv2d(x, wp, None, 1, 1), y_ref[:, :, pa::2, pb::2]) < 2e-6
+    prof = ops.PROFILER = ops.LaunchProfiler()
+    try:
+        y = ops.conv_fwd(_nhwc(x), _to_dev_ohwi(w), None, "c3up")
+        dy = torch.randn(B, Co, 2 * H, 2 * W, generator=gen)
+        dx = ops.conv_dgrad(_nhwc(dy), _to_dev_ohwi(w), "c3up", (H, W))
+    finally:
+        ops.PROFILER = None
+    assert len(prof.records) == 8 and all(r[0].startswith("conv3_tile_kernel") for r in prof.records)
+    assert _rel(_nchw(y), y_ref) < 2e-5
+    xr = x.clone().requires_grad_(True)
+    F.conv2d(F.interpolate(xr, scale_factor=2.0, mode="nearest"), w, None, 1, 1).backward(dy)
+    assert _rel(_nchw(dx), xr.grad) < 2e-5

@@ -45,7 +45,15 @@ __global__ __launch_bounds__(NT) void conv3_tile_kernel(vae_igemm_args p, int ti
   const int tile_lin = blockIdx.x / tilesN;
   const int y0 = ty * TH, x0 = tx * TW, n0 = tn * BN;
   // operand streams through buffer descriptors (common.h): the activation descriptor covers this tile's image
-  const auto rsA = VAE_BUF_RSRC(p.A + (int64_t)b * g.Hs * g.Ws * g.Cs, (size_t)g.Hs * g.Ws * g.Cs * 4u);
+  // sub-sampled views (phase convolutions, vaehip.h): pixel (y,x) of A is (y*as+aoy, x*as+aox) of a tensor `as` times larger
+  const int as = p.a_step > 1 ? p.a_step : 1, cs = p.c_step > 1 ? p.c_step : 1;
+  const size_t abytes = (size_t)(g.Hs * as) * (g.Ws * as) * g.Cs * 4u;
+  const auto rsA = VAE_BUF_RSRC(p.A + (int64_t)b * (g.Hs * as) * (g.Ws * as) * g.Cs, abytes);
+  // taps to compute, packed 4 bits each (all 9 unless tapmask selects a subset)
+  unsigned long long taplist = 0;
+  int ntaps = 0;
+  for (int tp = 0; tp < 9; ++tp)
+    if (p.tapmask == 0 || ((p.tapmask >> tp) & 1)) taplist |= (unsigned long long)tp << (4 * ntaps++);
   const auto rsW = VAE_BUF_RSRC(p.W, (size_t)(BKM ? p.K * p.sk : p.N * p.sn) * 4u);
   const int Hb = UP ? 2 * g.Hs : g.Hs, Wb = UP ? 2 * g.Ws : g.Ws;  // bounds of the (virtual) source grid
 
@@ -63,7 +71,7 @@ __global__ __launch_bounds__(NT) void conv3_tile_kernel(vae_igemm_args p, int ti
     for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
 
   const int kchunks = (p.K + BK - 1) / BK;
-  const int steps = 9 * kchunks;
+  const int steps = ntaps * kchunks;
 
   // ---- halo staging: thread owns float4 slots q = tid + NT*i ----
   f32x4 rh[HI];
@@ -80,7 +88,7 @@ __global__ __launch_bounds__(NT) void conv3_tile_kernel(vae_igemm_args p, int ti
       const int c = c0 + k4 * 4;
       const bool ok = (q < HQ) && ((unsigned)hy < (unsigned)Hb) && ((unsigned)hx < (unsigned)Wb) && (c < p.K);
       const int sy = UP ? (hy >> 1) : hy, sx = UP ? (hx >> 1) : hx;
-      rh[i] = VAE_BUF_LOAD4(rsA, ok ? (unsigned)(((sy * g.Ws + sx) * g.Cs + c) * 4) : BUF_OOB);
+      rh[i] = VAE_BUF_LOAD4(rsA, ok ? (unsigned)((((sy * as + p.a_oy) * (g.Ws * as) + sx * as + p.a_ox) * g.Cs + c) * 4) : BUF_OOB);
       hmask |= (ok ? 1 : 0) << i;
     }
   };
@@ -104,7 +112,7 @@ __global__ __launch_bounds__(NT) void conv3_tile_kernel(vae_igemm_args p, int ti
   f32x4 rw[BR];
   const int k4w = tid & 7, r0w = tid >> 3;
   auto load_w = [&](int s) {
-    const int cch = s / 9, tap = s - cch * 9;
+    const int cch = s / ntaps, tap = (int)((taplist >> (4 * (s - cch * ntaps))) & 15);
     const int c0 = cch * BK;
     if (!BKM) {
       const int c = c0 + k4w * 4;
@@ -172,13 +180,14 @@ __global__ __launch_bounds__(NT) void conv3_tile_kernel(vae_igemm_args p, int ti
   store_w(sBst);
   if (steps > 1) load_w(1);
   __syncthreads();
-  int cch = 0, tap = 0;
+  int cch = 0, ti = 0;
   for (int s = 0; s < steps; ++s) {
+    const int tap = (int)((taplist >> (4 * ti)) & 15);
     const int kh = tap / 3, kw = tap - kh * 3;
     const int dy = DG ? 2 - kh : kh, dx = DG ? 2 - kw : kw;
     const float* cA = sH + ((wm + dy) * HW_ + lr + dx) * LDA;
     const float* cB = sBst + (s & 1) * SB;
-    if (tap == 0 && cch + 1 < kchunks) load_halo((cch + 1) * BK);  // lands during this chunk's 9 taps
+    if (ti == 0 && cch + 1 < kchunks) load_halo((cch + 1) * BK);  // lands during this chunk's taps
     fetch(cA, cB, 0, fa[0], fb[0]);
     compute(cA, cB, 0);
     compute(cA, cB, 1);
@@ -189,8 +198,8 @@ __global__ __launch_bounds__(NT) void conv3_tile_kernel(vae_igemm_args p, int ti
     compute(cA, cB, 2);
     compute(cA, cB, 3);
     __syncthreads();
-    if (++tap == 9) {
-      tap = 0;
+    if (++ti == ntaps) {
+      ti = 0;
       if (++cch < kchunks) {  // every wave has left the old halo (barrier above): restage it for the next chunk
         store_halo();
         __syncthreads();
@@ -202,9 +211,9 @@ __global__ __launch_bounds__(NT) void conv3_tile_kernel(vae_igemm_args p, int ti
   // outputs and the residual through buffer descriptors over this tile's image: out-of-range = load 0 / store dropped,
   // so the 16 residual loads of a block are issued back to back and there is no branch per element
   const int oy = y0 + wm;
-  const size_t obytes = (size_t)g.Ho * g.Wo * p.ldc * 4u;
-  const auto rsC = VAE_BUF_RSRC(p.C + (int64_t)b * g.Ho * g.Wo * p.ldc, obytes);
-  const auto rsR = VAE_BUF_RSRC((p.res ? p.res : p.C) + (int64_t)b * g.Ho * g.Wo * p.ldc, obytes);
+  const size_t obytes = (size_t)(g.Ho * cs) * (g.Wo * cs) * p.ldc * 4u;
+  const auto rsC = VAE_BUF_RSRC(p.C + (int64_t)b * (g.Ho * cs) * (g.Wo * cs) * p.ldc, obytes);
+  const auto rsR = VAE_BUF_RSRC((p.res ? p.res : p.C) + (int64_t)b * (g.Ho * cs) * (g.Wo * cs) * p.ldc, obytes);
   float tsum[2] = {0.f, 0.f}, gs1[2] = {0.f, 0.f}, gs2[2] = {0.f, 0.f};
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
@@ -216,7 +225,7 @@ __global__ __launch_bounds__(NT) void conv3_tile_kernel(vae_igemm_args p, int ti
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int ox = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      off[r] = (colok && ox < g.Wo) ? (unsigned)(((oy * g.Wo + ox) * p.ldc + col) * 4) : BUF_OOB;
+      off[r] = (colok && ox < g.Wo) ? (unsigned)((((oy * cs + p.c_oy) * (g.Wo * cs) + ox * cs + p.c_ox) * p.ldc + col) * 4) : BUF_OOB;
       rv[r] = 0.f;
     }
     if (p.res) {  // uniform
@@ -291,7 +300,8 @@ bool conv3_tile_eligible(const vae_igemm_args& a, bool vec, bool bkm) {
   const vae_conv_geom& g = a.g;
   if (!vec || a.batch != 1 || g.taps != 9 || g.stride != 1 || g.pad_t != 1 || g.pad_l != 1) return false;
   if (a.N <= 32 || a.K % 4 != 0 || a.alpha != 1.0f) return false;
-  if ((size_t)g.Hs * g.Ws * g.Cs * 4u >= BUF_MAX || (size_t)g.Ho * g.Wo * a.ldc * 4u >= BUF_MAX) return false;  // one image per descriptor
+  const size_t as = a.a_step > 1 ? a.a_step : 1, cs = a.c_step > 1 ? a.c_step : 1;
+  if ((size_t)g.Hs * g.Ws * g.Cs * 4u * as * as >= BUF_MAX || (size_t)g.Ho * g.Wo * a.ldc * 4u * cs * cs >= BUF_MAX) return false;  // one image per descriptor
   if ((size_t)std::max((int64_t)a.K * a.sk, (int64_t)a.N * a.sn) * 4u >= BUF_MAX) return false;
   if (g.Wo % TW != 0 || g.Ho % TH != 0) return false;
   if (a.xf != VAE_XF_NONE && (a.K > SS_HALF || bkm)) return false;
@@ -304,7 +314,7 @@ bool conv3_tile_eligible(const vae_igemm_args& a, bool vec, bool bkm) {
 // chunks per image of the statistics epilogue (0 = not available for these arguments)
 int conv3_tile_gstat_chunks(const vae_igemm_args& a) {
   const vae_conv_geom& g = a.g;
-  if (a.gstat_groups <= 0 || a.N % BN != 0 || a.N % a.gstat_groups != 0 || g.mode == VAE_MODE_DGRAD) return 0;
+  if (a.gstat_groups <= 0 || a.N % BN != 0 || a.N % a.gstat_groups != 0 || g.mode == VAE_MODE_DGRAD || a.c_step > 1) return 0;
   const int cpg = a.N / a.gstat_groups;
   if (cpg != 4 && cpg != 8 && cpg != 16) return 0;
   return (g.Wo / TW) * (g.Ho / TH);

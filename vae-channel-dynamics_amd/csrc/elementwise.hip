@@ -202,6 +202,39 @@ __global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict_
   }
 }
 
+// effective 3x3 kernels of conv3x3(nearest_upsample_2x(x)) on the low-resolution x, one per output parity (vaehip.h)
+__global__ __launch_bounds__(256) void upconv_phase_weights_kernel(const float* __restrict__ W, int Co, int Ci, float* __restrict__ We) {
+  const int64_t n = (int64_t)Co * Ci;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int co = (int)(i / Ci), ci = (int)(i - (int64_t)co * Ci);
+    float w[3][3];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) w[kh][kw] = W[((int64_t)co * 9 + kh * 3 + kw) * Ci + ci];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        // parity a: upsampled rows 2i+a+kh-1 -> low rows {i-1: kh0 | i: kh1,kh2} (a=0), {i: kh0,kh1 | i+1: kh2} (a=1)
+        float r[3][3];  // row-combined [kh'][kw]
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          r[0][kw] = a == 0 ? w[0][kw] : 0.f;
+          r[1][kw] = a == 0 ? w[1][kw] + w[2][kw] : w[0][kw] + w[1][kw];
+          r[2][kw] = a == 0 ? 0.f : w[2][kw];
+        }
+        float* o = We + (((int64_t)(a * 2 + b) * Co + co) * 9) * Ci + ci;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          o[(int64_t)(kh * 3 + 0) * Ci] = b == 0 ? r[kh][0] : 0.f;
+          o[(int64_t)(kh * 3 + 1) * Ci] = b == 0 ? r[kh][1] + r[kh][2] : r[kh][0] + r[kh][1];
+          o[(int64_t)(kh * 3 + 2) * Ci] = b == 0 ? 0.f : r[kh][2];
+        }
+      }
+  }
+}
+
 // ---------------- grad norm + AdamW ----------------
 __global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ ws) {
   __shared__ float red[4];
@@ -386,6 +419,13 @@ extern "C" int vae_add(const float* a, const float* b, int64_t n, float* out, vo
   VAE_CHECK(a && b && out && n > 0, "add: bad args");
   hipLaunchKernelGGL(add_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, n, out);
   VAE_LAUNCH_CHECK("add");
+  return VAE_OK;
+}
+
+extern "C" int vae_upconv_phase_weights(const float* W, int32_t Co, int32_t Ci, float* Weff, void* stream) {
+  VAE_CHECK(W && Weff && Co > 0 && Ci > 0, "upconv_phase_weights: bad args");
+  hipLaunchKernelGGL(upconv_phase_weights_kernel, dim3(ew_blocks((int64_t)Co * Ci)), dim3(256), 0, (hipStream_t)stream, W, Co, Ci, Weff);
+  VAE_LAUNCH_CHECK("upconv_phase_weights");
   return VAE_OK;
 }
 

@@ -27,6 +27,8 @@ class IgemmArgs(C.Structure):
                 ("ldc", C.c_int32), ("sn", C.c_int64), ("sk", C.c_int64), ("st", C.c_int64),
                 ("batch", C.c_int32), ("sAb", C.c_int64), ("sWb", C.c_int64), ("sCb", C.c_int64),
                 ("xf", C.c_int32), ("alpha", C.c_float), ("prec", C.c_int32), ("Wh", _fp), ("A16", _fp),
+                ("tapmask", C.c_int32), ("a_step", C.c_int32), ("a_oy", C.c_int32), ("a_ox", C.c_int32),
+                ("c_step", C.c_int32), ("c_oy", C.c_int32), ("c_ox", C.c_int32),
                 ("gstat", _fp), ("gstat_groups", C.c_int32)]
 
 
@@ -38,12 +40,14 @@ class WgradArgs(C.Structure):
 
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
-EXPECTED_ABI = 4  # vae_abi_version() of the library these structures and signatures describe
+EXPECTED_ABI = 5  # vae_abi_version() of the library these structures and signatures describe
 
 # name -> argtypes (every function returns int); must list EVERY symbol of include/vaehip.h
 SIGNATURES = {
     "vae_igemm_rows": [C.POINTER(IgemmArgs), vp],
     "vae_conv_gstat_chunks": [C.POINTER(IgemmArgs)],
+    "vae_conv_phase_ok": [C.POINTER(IgemmArgs)],
+    "vae_upconv_phase_weights": [vp, i32, i32, vp, vp],
     "vae_wgrad": [C.POINTER(WgradArgs), vp],
     "vae_xf_fusable_rows": [C.POINTER(ConvGeom), i32, i32],
     "vae_wgrad_plan": [C.POINTER(WgradArgs), C.POINTER(i32), C.POINTER(i32)],

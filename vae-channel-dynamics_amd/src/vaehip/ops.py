@@ -94,7 +94,9 @@ def _launch_igemm(a: IgemmArgs):
     e0.record()
     lib.call("vae_igemm_rows", C.byref(a), _stream())
     e1.record()
-    taps = 2.25 if a.g.mode == MODE_DGRAD_S2 else a.g.taps  # algorithmic taps per row
+    # taps per row the launch really multiplies (the roofline figure prices executed MFMA work): the parity-class stride-2
+    # dgrad meets 9/4 taps per row on average, a phase convolution of an upsampler only those of its tap mask
+    taps = 2.25 if a.g.mode == MODE_DGRAD_S2 else (bin(a.tapmask).count("1") if a.tapmask else a.g.taps)
     PROFILER.records.append((_kernel_name("vae_igemm_kernel_name", a), 2.0 * a.M * a.N * a.K * taps * a.batch, e0, e1))
 
 
@@ -187,6 +189,87 @@ def gn_apply_bf16(x: torch.Tensor, st: "Stats", xf: int) -> torch.Tensor:
     return y
 
 
+# conv3x3(nearest_upsample_2x(x)) as four phase convolutions on the low-resolution x (2x2 effective kernels: 16 instead
+# of 36 tap-MACs per low-resolution pixel, forward and dgrad); False = the virtual-upsample kernel
+PHASE_UPCONV = True
+_PHASE_MASK = {0: (0, 1), 1: (1, 2)}  # parity -> rows (columns) of the 3x3 window on the low-resolution grid
+
+
+def _phase_tapmask(pa: int, pb: int) -> int:
+    return sum(1 << (kh * 3 + kw) for kh in _PHASE_MASK[pa] for kw in _PHASE_MASK[pb])
+
+
+def upconv_phase_weights(wv: torch.Tensor) -> torch.Tensor:
+    """wv: OHWI memory [Co,3,3,Ci] -> [4,Co,3,3,Ci] effective kernels per output parity (vae_upconv_phase_weights)."""
+    Co, kh, kw, Ci = wv.shape
+    we = torch.empty((4, Co, 3, 3, Ci), device=wv.device, dtype=torch.float32)
+    lib.call("vae_upconv_phase_weights", _p(wv), Co, Ci, _p(we), _stream())
+    return we
+
+
+def _phase_args(x_lo_shape, Co, Ci, dgrad: bool) -> IgemmArgs:
+    """argument block of one phase convolution on the low-resolution grid (pointers / views filled by the caller)"""
+    B, H, W, _ = x_lo_shape
+    a = IgemmArgs()
+    if not dgrad:
+        a.g = ConvGeom(B, H, W, Ci, H, W, 9, 1, 1, 1, MODE_FWD)
+        a.M, a.N, a.K, a.ldc = B * H * W, Co, Ci, Co
+        a.sn, a.sk, a.st = 9 * Ci, 1, Ci
+    else:
+        a.g = ConvGeom(B, H, W, Co, H, W, 9, 1, 1, 1, MODE_DGRAD)
+        a.M, a.N, a.K, a.ldc = B * H * W, Ci, Co, Ci
+        a.sn, a.sk, a.st = 1, 9 * Ci, Ci
+    a.batch, a.sAb, a.sWb, a.sCb = 1, 0, 0, 0
+    a.xf, a.alpha, a.prec = XF_NONE, 1.0, PREC_F32
+    return a
+
+
+def _upconv_phase_fwd(x, wv, bias):
+    """-> [B,2H,2W,Co] or None when the halo-tile kernel does not serve the low-resolution geometry"""
+    B, H, W, Cs = x.shape
+    Co, _, _, Ci = wv.shape
+    if Cs != Ci:
+        return None
+    a = _phase_args(x.shape, Co, Ci, False)
+    a.A, a.W = _p(x), _p(wv)
+    out = torch.empty((B, 2 * H, 2 * W, Co), device=x.device, dtype=torch.float32)
+    a.C, a.bias = _p(out), _p(bias)
+    a.c_step = 2
+    if not lib.query("vae_conv_phase_ok", C.byref(a)):
+        return None
+    we = upconv_phase_weights(wv)
+    for pa in (0, 1):
+        for pb in (0, 1):
+            a.W = _p(we[pa * 2 + pb])
+            a.tapmask, a.c_oy, a.c_ox = _phase_tapmask(pa, pb), pa, pb
+            _launch_igemm(a)
+    return out
+
+
+def _upconv_phase_dgrad(dy, wv, in_hw):
+    """dy [B,2H,2W,Co] -> gradient wrt the LOW-resolution input [B,H,W,Ci] (no high-resolution intermediate), or None"""
+    B, Hy, Wy, Co = dy.shape
+    H, W = in_hw
+    _, _, _, Ci = wv.shape
+    a = _phase_args((B, H, W, Ci), Co, Ci, True)
+    a.A, a.W = _p(dy), _p(wv)
+    out = torch.empty((B, H, W, Ci), device=dy.device, dtype=torch.float32)
+    a.C = _p(out)
+    a.a_step = 2
+    if not lib.query("vae_conv_phase_ok", C.byref(a)):
+        return None
+    we = upconv_phase_weights(wv)
+    first = True
+    for pa in (0, 1):
+        for pb in (0, 1):
+            a.W = _p(we[pa * 2 + pb])
+            a.tapmask, a.a_oy, a.a_ox = _phase_tapmask(pa, pb), pa, pb
+            a.res = None if first else _p(out)  # the four phases add up
+            _launch_igemm(a)
+            first = False
+    return out
+
+
 def conv_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], kind: str, *,
              xf: int = XF_NONE, stats: Optional[Stats] = None, res: Optional[torch.Tensor] = None,
              track: Optional[torch.Tensor] = None, a16: Optional[torch.Tensor] = None,
@@ -199,6 +282,11 @@ def conv_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], kin
     if a16 is not None:
         assert a16.shape == x.shape and a16.dtype == torch.bfloat16 and a16.is_contiguous()
         xf = XF_NONE
+    if (kind == "c3up" and PHASE_UPCONV and PRECISION == PREC_F32 and xf == XF_NONE and res is None and track is None
+            and a16 is None):
+        out = _upconv_phase_fwd(x, ohwi(w), bias)
+        if out is not None:
+            return out
     wv = ohwi(w)
     Co, kh, kw, Ci = wv.shape
     B, H, W, Cs = x.shape
@@ -244,6 +332,10 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, kind: str, in_hw: Tuple[int, i
     B, Hy, Wy, Cy = dy.shape
     assert Cy == Co
     H, W = in_hw
+    if kind == "c3up" and PHASE_UPCONV and PRECISION == PREC_F32:
+        out = _upconv_phase_dgrad(dy, wv, in_hw)
+        if out is not None:
+            return out
     if kind == "c3up":
         Hr, Wr, stride, pad = 2 * H, 2 * W, 1, 1
     elif kind == "c3s2":
