@@ -135,8 +135,17 @@ typedef struct vae_wgrad_args {
   float alpha;
   int32_t prec;          /* VAE_PREC_* */
   const void* X16;       /* optional: as vae_igemm_args.A16, for X (xf must be NONE) */
+  /* phase convolutions of an upsampler (vae_wgrad_phase_ok(a) != 0; zero-initialised = plain): pixel (y,x) of dY lives at
+   * (y*y_step + y_oy, x*y_step + y_ox) of a tensor y_step times larger in H and W; only the taps in tapmask are computed
+   * (the others are written as zeros).  vae_upconv_fold_wgrad turns the four phase results into the 3x3 gradient.     */
+  int32_t tapmask;
+  int32_t y_step, y_oy, y_ox;
 } vae_wgrad_args;
 int vae_wgrad(const vae_wgrad_args* a, void* stream);
+/* 1 when the kernel serving `a` honours tapmask / y_step.. (the fp32 halo-tile wgrad kernel)                       */
+int vae_wgrad_phase_ok(const vae_wgrad_args* a);
+/* transpose of vae_upconv_phase_weights: dWeff [4][Co][3][3][Ci] (+ dbeff [4][Co] or NULL) -> dW [Co][3][3][Ci] (+ db) */
+int vae_upconv_fold_wgrad(const float* dWeff, const float* dbeff, int32_t Co, int32_t Ci, float* dW, float* db, void* stream);
 /* split-K plan for `a` (a->nsplit ignored): the nsplit to launch with, and whether a->xf can be fused
  * (0 => materialise XF(X) with vae_gn_apply and pass xf = NONE; only tiny spatial sizes).                */
 int vae_wgrad_plan(const vae_wgrad_args* a, int32_t* nsplit, int32_t* xf_fusable);

@@ -565,10 +565,17 @@ def test_upconv_phase_decomposition(cuda):
         y = ops.conv_fwd(_nhwc(x), _to_dev_ohwi(w), None, "c3up")
         dy = torch.randn(B, Co, 2 * H, 2 * W, generator=gen)
         dx = ops.conv_dgrad(_nhwc(dy), _to_dev_ohwi(w), "c3up", (H, W))
+        gw = torch.full_like(_to_dev_ohwi(w).permute(0, 2, 3, 1).contiguous(), float("nan")).permute(0, 3, 1, 2)
+        gb = torch.full((Co,), float("nan"), device="cuda")
+        ops.conv_wgrad(_nhwc(dy), _nhwc(x), "c3up", gw, gb)
     finally:
         ops.PROFILER = None
-    assert len(prof.records) == 8 and all(r[0].startswith("conv3_tile_kernel") for r in prof.records)
+    assert len(prof.records) == 12 and all(r[0].startswith("conv3_tile_kernel") for r in prof.records[:8])
+    assert all(r[0].startswith("wgrad3_tile_kernel") for r in prof.records[8:])
     assert _rel(_nchw(y), y_ref) < 2e-5
     xr = x.clone().requires_grad_(True)
-    F.conv2d(F.interpolate(xr, scale_factor=2.0, mode="nearest"), w, None, 1, 1).backward(dy)
+    wr = w.clone().requires_grad_(True)
+    F.conv2d(F.interpolate(xr, scale_factor=2.0, mode="nearest"), wr, None, 1, 1).backward(dy)
     assert _rel(_nchw(dx), xr.grad) < 2e-5
+    assert _rel(gw.cpu(), wr.grad) < 3e-5
+    assert _rel(gb.cpu(), dy.sum(dim=(0, 2, 3))) < 3e-5

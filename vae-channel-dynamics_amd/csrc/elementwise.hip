@@ -235,6 +235,31 @@ __global__ __launch_bounds__(256) void upconv_phase_weights_kernel(const float* 
   }
 }
 
+// transpose of upconv_phase_weights_kernel: every original tap (kh,kw) collects the effective tap it went into, in each phase
+__global__ __launch_bounds__(256) void upconv_fold_wgrad_kernel(const float* __restrict__ dWe, const float* __restrict__ dbe, int Co,
+                                                                int Ci, float* __restrict__ dW, float* __restrict__ db) {
+  const int64_t n = (int64_t)Co * Ci, slab = (int64_t)Co * 9 * Ci;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int co = (int)(i / Ci), ci = (int)(i - (int64_t)co * Ci);
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        float t = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const int khe = a == 0 ? (kh == 0 ? 0 : 1) : (kh == 2 ? 2 : 1);
+            const int kwe = b == 0 ? (kw == 0 ? 0 : 1) : (kw == 2 ? 2 : 1);
+            t += dWe[(a * 2 + b) * slab + ((int64_t)co * 9 + khe * 3 + kwe) * Ci + ci];
+          }
+        dW[((int64_t)co * 9 + kh * 3 + kw) * Ci + ci] = t;
+      }
+    if (db && dbe && ci == 0) db[co] = (dbe[co] + dbe[Co + co]) + (dbe[2 * Co + co] + dbe[3 * Co + co]);
+  }
+}
+
 // ---------------- grad norm + AdamW ----------------
 __global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ ws) {
   __shared__ float red[4];
@@ -426,6 +451,14 @@ extern "C" int vae_upconv_phase_weights(const float* W, int32_t Co, int32_t Ci, 
   VAE_CHECK(W && Weff && Co > 0 && Ci > 0, "upconv_phase_weights: bad args");
   hipLaunchKernelGGL(upconv_phase_weights_kernel, dim3(ew_blocks((int64_t)Co * Ci)), dim3(256), 0, (hipStream_t)stream, W, Co, Ci, Weff);
   VAE_LAUNCH_CHECK("upconv_phase_weights");
+  return VAE_OK;
+}
+
+extern "C" int vae_upconv_fold_wgrad(const float* dWeff, const float* dbeff, int32_t Co, int32_t Ci, float* dW, float* db, void* stream) {
+  VAE_CHECK(dWeff && dW && Co > 0 && Ci > 0, "upconv_fold_wgrad: bad args");
+  hipLaunchKernelGGL(upconv_fold_wgrad_kernel, dim3(ew_blocks((int64_t)Co * Ci)), dim3(256), 0, (hipStream_t)stream, dWeff, dbeff, Co,
+                     Ci, dW, db);
+  VAE_LAUNCH_CHECK("upconv_fold_wgrad");
   return VAE_OK;
 }
 

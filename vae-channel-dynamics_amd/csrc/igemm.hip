@@ -619,6 +619,7 @@ static bool wgrad_vec(const vae_wgrad_args& a) {
   if (a.xf != VAE_XF_NONE) vec = vec && aligned16(a.scale) && aligned16(a.shift);
   return vec;
 }
+static bool wgrad_is_phase(const vae_wgrad_args& a) { return a.tapmask != 0 || a.y_step > 1; }
 static bool wgrad_use_tile(const vae_wgrad_args& a) { return wgrad3_tile_eligible(a, wgrad_vec(a)) && !getenv("VAEHIP_FLAT_CONV"); }
 static bool wgrad_use_tile_bf16(const vae_wgrad_args& a) {
   return a.prec == VAE_PREC_BF16 && wgrad3_tile_bf16_eligible(a, wgrad_vec(a)) && !getenv("VAEHIP_FLAT_CONV");
@@ -638,12 +639,12 @@ extern "C" int vae_wgrad_plan(const vae_wgrad_args* ap, int32_t* nsplit, int32_t
     const int64_t per_max = std::max<int64_t>(1, (nb_max - 1) * upi);
     return (units + per_max - 1) / per_max;
   };
-  if (wgrad_smallk_kind(a)) {  // <= 4-channel side: one slab per workgroup, 128-pixel tiles dealt out in ranges
+  if (!wgrad_is_phase(a) && wgrad_smallk_kind(a)) {  // <= 4-channel side: one slab per workgroup, 128-pixel tiles dealt out in ranges
     *nsplit = (int32_t)std::max(1, std::min(1024, wgrad_smallk_tiles(a)));
     *xf_fusable = 1;
     return VAE_OK;
   }
-  if (wgrad_use_tile_bf16(a)) {
+  if (!wgrad_is_phase(a) && wgrad_use_tile_bf16(a)) {
     const int64_t units = wgrad3_tile_bf16_units(a.g);
     const int64_t cols = wgrad3_tile_bf16_columns(a);
     int64_t ns = std::max<int64_t>(1, std::min<int64_t>(256 / std::max<int64_t>(cols, 1), units / 4));
@@ -748,7 +749,8 @@ extern "C" int vae_wgrad_kernel_name(const vae_wgrad_args* ap, char* buf, int32_
   const vae_wgrad_args& a = *ap;
   const bool vec = wgrad_vec(a);
   const char* tf[2] = {"false", "true"};
-  if (wgrad_smallk_kind(a)) snprintf(buf, n, "wgrad_smallk_kernel<%s,%d>", tf[wgrad_smallk_kind(a) == 1], a.xf);
+  if (wgrad_is_phase(a)) snprintf(buf, n, "wgrad3_tile_kernel<%s,%d>", tf[a.g.mode == VAE_MODE_UP2X], a.xf);
+  else if (wgrad_smallk_kind(a)) snprintf(buf, n, "wgrad_smallk_kernel<%s,%d>", tf[wgrad_smallk_kind(a) == 1], a.xf);
   else if (wgrad_use_tile_bf16(a)) snprintf(buf, n, "wgrad3_tile_bf16_kernel<%s,%d,%s>", tf[a.g.mode == VAE_MODE_UP2X], a.xf, tf[a.X16 != nullptr]);
   else if (wgrad_use_tile(a)) snprintf(buf, n, "wgrad3_tile_kernel<%s,%d>", tf[a.g.mode == VAE_MODE_UP2X], a.xf);
   else if (a.prec == VAE_PREC_BF16 && vec)
@@ -824,6 +826,9 @@ extern "C" int vae_igemm_rows(const vae_igemm_args* ap, void* stream) {
   return VAE_OK;
 }
 
+extern "C" int vae_wgrad_phase_ok(const vae_wgrad_args* ap) {
+  return (ap && ap->prec != VAE_PREC_BF16 && ap->X16 == nullptr && wgrad_use_tile(*ap) && !wgrad_smallk_kind(*ap)) ? 1 : 0;
+}
 extern "C" int vae_wgrad(const vae_wgrad_args* ap, void* stream) {
   VAE_CHECK(ap != nullptr, "wgrad: null args");
   const vae_wgrad_args& a = *ap;
@@ -840,6 +845,13 @@ extern "C" int vae_wgrad(const vae_wgrad_args* ap, void* stream) {
   const bool vec = wgrad_vec(a);
   hipStream_t st = (hipStream_t)stream;
   VAE_CHECK(a.prec == VAE_PREC_F32 || a.prec == VAE_PREC_BF16, "wgrad: bad prec %d", a.prec);
+  if (wgrad_is_phase(a)) {  // sub-sampled dY / tap subsets: only the fp32 halo-tile kernel implements them
+    VAE_CHECK(vae_wgrad_phase_ok(ap), "wgrad: tapmask / y_step need the fp32 halo-tile kernel (vae_wgrad_phase_ok)");
+    VAE_CHECK(a.nsplit <= 65535, "wgrad: nsplit too large");
+    if (int rc2 = launch_wgrad3_tile(a, st)) return rc2;
+    VAE_LAUNCH_CHECK("wgrad3_tile");
+    return VAE_OK;
+  }
   if (a.X16 == nullptr && wgrad_smallk_kind(a)) {
     VAE_CHECK(a.nsplit <= 65535, "wgrad: nsplit too large");
     if (int rc2 = launch_wgrad_smallk(a, st)) return rc2;

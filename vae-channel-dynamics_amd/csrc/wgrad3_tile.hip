@@ -50,6 +50,11 @@ __global__ __launch_bounds__(NT) void wgrad3_tile_kernel(vae_wgrad_args p, int x
   const int nu = (int)max((int64_t)0, uend - ubeg);
   const int Hb = UP ? 2 * g.Hs : g.Hs, Wb = UP ? 2 * g.Ws : g.Ws;
   const bool do_bias = (p.bias_partial != nullptr) && tn == 0;
+  // phase convolutions (vaehip.h): dY is a sub-sampled view, and only the taps of tapmask are computed -- a wave whose kernel
+  // row is masked out only helps with the staging, the others skip the masked columns
+  const int ys = p.y_step > 1 ? p.y_step : 1;
+  const int tmask = p.tapmask ? p.tapmask : 0x1ff;
+  const int wmask = (tmask >> (3 * tg)) & 7;  // this wave's kernel row: bit t = tap (kh = tg, kw = t)
   const int rows_per_img = (g.Ho / TH) * xblocks;  // units per image
 
   const int b_lo = nu > 0 ? (int)(ubeg / rows_per_img) : 0;
@@ -81,13 +86,13 @@ __global__ __launch_bounds__(NT) void wgrad3_tile_kernel(vae_wgrad_args p, int x
     const int ty = rem / xblocks, xb = rem - ty * xblocks;
     const int y = ty * TH;  // first output row of the unit
     // buffer descriptors (common.h) over this unit's image of dY and of X: out-of-range offsets read zeros
-    const auto rsY = VAE_BUF_RSRC(p.dY + (int64_t)b * g.Ho * g.Wo * p.ldy, (size_t)g.Ho * g.Wo * p.ldy * 4u);
+    const auto rsY = VAE_BUF_RSRC(p.dY + (int64_t)b * (g.Ho * ys) * (g.Wo * ys) * p.ldy, (size_t)(g.Ho * ys) * (g.Wo * ys) * p.ldy * 4u);
     const auto rsX = VAE_BUF_RSRC(p.X + (int64_t)b * g.Hs * g.Ws * g.Cs, (size_t)g.Hs * g.Ws * g.Cs * 4u);
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       const int q = tid + NT * i;
       const int k = q >> 5;  // pixel of the unit: (row k / TW, col k % TW)
-      const int pix = (y + k / TW) * g.Wo + xb * TW + (k % TW);
+      const int pix = ((y + k / TW) * ys + p.y_oy) * (g.Wo * ys) + (xb * TW + (k % TW)) * ys + p.y_ox;  // sub-sampled view of dY
       const int c = m0 + a4 * 4;
       ra[i] = VAE_BUF_LOAD4(rsY, (q < AQ && c < p.M) ? (unsigned)((pix * p.ldy + c) * 4) : BUF_OOB);
     }
@@ -149,9 +154,11 @@ __global__ __launch_bounds__(NT) void wgrad3_tile_kernel(vae_wgrad_args p, int x
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t = 0; t < 3; ++t)
+        if ((wmask >> t) & 1) {  // wave-uniform
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][j], fb[kk & 1][t][j], acc[t], 0, 0, 0);
+          for (int j = 0; j < 4; ++j)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][j], fb[kk & 1][t][j], acc[t], 0, 0, 0);
+        }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -213,7 +220,8 @@ bool wgrad3_tile_eligible(const vae_wgrad_args& a, bool vec) {
   if (g.mode == VAE_MODE_FWD && !(g.Ho == g.Hs && g.Wo == g.Ws)) return false;
   if (g.mode == VAE_MODE_UP2X && !(g.Ho == 2 * g.Hs && g.Wo == 2 * g.Ws)) return false;
   if (g.mode == VAE_MODE_DGRAD) return false;
-  if ((size_t)g.Ho * g.Wo * a.ldy * 4u >= BUF_MAX || (size_t)g.Hs * g.Ws * g.Cs * 4u >= BUF_MAX) return false;  // one image per descriptor
+  const size_t ys = a.y_step > 1 ? a.y_step : 1;
+  if ((size_t)g.Ho * g.Wo * a.ldy * 4u * ys * ys >= BUF_MAX || (size_t)g.Hs * g.Ws * g.Cs * 4u >= BUF_MAX) return false;  // one image per descriptor
   return true;
 }
 

@@ -36,7 +36,8 @@ class WgradArgs(C.Structure):
     _fields_ = [("dY", _fp), ("X", _fp), ("out", _fp), ("partial", _fp), ("bias_partial", _fp), ("scale", _fp), ("shift", _fp),
                 ("g", ConvGeom), ("M", C.c_int32), ("N", C.c_int32), ("ldy", C.c_int32), ("npix", C.c_int32),
                 ("nsplit", C.c_int32), ("batch", C.c_int32), ("sYb", C.c_int64), ("sXb", C.c_int64),
-                ("sOb", C.c_int64), ("xf", C.c_int32), ("alpha", C.c_float), ("prec", C.c_int32), ("X16", _fp)]
+                ("sOb", C.c_int64), ("xf", C.c_int32), ("alpha", C.c_float), ("prec", C.c_int32), ("X16", _fp),
+                ("tapmask", C.c_int32), ("y_step", C.c_int32), ("y_oy", C.c_int32), ("y_ox", C.c_int32)]
 
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
@@ -48,6 +49,8 @@ SIGNATURES = {
     "vae_conv_gstat_chunks": [C.POINTER(IgemmArgs)],
     "vae_conv_phase_ok": [C.POINTER(IgemmArgs)],
     "vae_upconv_phase_weights": [vp, i32, i32, vp, vp],
+    "vae_wgrad_phase_ok": [C.POINTER(WgradArgs)],
+    "vae_upconv_fold_wgrad": [vp, vp, i32, i32, vp, vp, vp],
     "vae_wgrad": [C.POINTER(WgradArgs), vp],
     "vae_xf_fusable_rows": [C.POINTER(ConvGeom), i32, i32],
     "vae_wgrad_plan": [C.POINTER(WgradArgs), C.POINTER(i32), C.POINTER(i32)],

@@ -108,7 +108,8 @@ def _launch_wgrad(a: WgradArgs):
     e0.record()
     lib.call("vae_wgrad", C.byref(a), _stream())
     e1.record()
-    PROFILER.records.append((_kernel_name("vae_wgrad_kernel_name", a), 2.0 * a.M * a.N * a.npix * a.g.taps * a.batch, e0, e1))
+    taps = bin(a.tapmask).count("1") if a.tapmask else a.g.taps  # executed taps (phase convolutions compute 4 of 9)
+    PROFILER.records.append((_kernel_name("vae_wgrad_kernel_name", a), 2.0 * a.M * a.N * a.npix * taps * a.batch, e0, e1))
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -364,6 +365,49 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, kind: str, in_hw: Tuple[int, i
     return out
 
 
+def _upconv_phase_wgrad(dy, x, gv, bgrad_out) -> bool:
+    """weight (and bias) gradient of conv3x3(nearest_upsample_2x(x)) from four phase weight gradients on the low-resolution
+    grid (each computes the 4 taps of its 2x2 effective kernel), folded back into the 3x3 gradient; False = not served"""
+    Co, _, _, Ci = gv.shape
+    B, H, W, Cs = x.shape
+    if Cs != Ci:
+        return False
+    a = WgradArgs()
+    a.dY, a.X = _p(dy), _p(x)
+    a.g = ConvGeom(B, H, W, Cs, H, W, 9, 1, 1, 1, MODE_FWD)
+    a.M, a.N, a.ldy, a.npix, a.nsplit = Co, Ci, Co, B * H * W, 1
+    a.batch, a.sYb, a.sXb, a.sOb = 1, 0, 0, 0
+    a.xf, a.alpha, a.prec = XF_NONE, 1.0, PREC_F32
+    a.y_step, a.tapmask = 2, _phase_tapmask(0, 0)
+    if not lib.query("vae_wgrad_phase_ok", C.byref(a)):
+        return False
+    ns, fus = C.c_int32(0), C.c_int32(0)
+    lib.call("vae_wgrad_plan", C.byref(a), C.byref(ns), C.byref(fus))
+    ns = ns.value
+    a.nsplit = ns
+    n = Co * 9 * Ci
+    dwe = torch.empty((4, n), device=x.device, dtype=torch.float32)
+    dbe = torch.empty((4, Co), device=x.device, dtype=torch.float32) if bgrad_out is not None else None
+    partial = torch.empty((ns, n), device=x.device, dtype=torch.float32) if ns > 1 else None
+    bpart = torch.empty((ns, Co), device=x.device, dtype=torch.float32) if bgrad_out is not None else None
+    for pa in (0, 1):
+        for pb in (0, 1):
+            ph = pa * 2 + pb
+            a.tapmask, a.y_oy, a.y_ox = _phase_tapmask(pa, pb), pa, pb
+            if ns == 1:
+                a.out = _p(dwe[ph])
+            else:
+                a.partial = _p(partial)
+            a.bias_partial = _p(bpart)
+            _launch_wgrad(a)
+            if ns > 1:
+                lib.call("vae_reduce_splits", _p(partial), ns, n, _p(dwe[ph]), _stream())
+            if bpart is not None:
+                lib.call("vae_reduce_splits", _p(bpart), ns, Co, _p(dbe[ph]), _stream())
+    lib.call("vae_upconv_fold_wgrad", _p(dwe), _p(dbe), Co, Ci, _p(gv), _p(bgrad_out), _stream())
+    return True
+
+
 def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, kind: str, wgrad_out: torch.Tensor,
                bgrad_out: Optional[torch.Tensor], *, xf: int = XF_NONE, stats: Optional[Stats] = None,
                x16: Optional[torch.Tensor] = None):
@@ -380,6 +424,9 @@ def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, kind: str, wgrad_out: torch.Te
     B, H, W, Cs = x.shape
     g = _fwd_geom(kind, B, H, W, Cs)
     assert dy.shape == (B, g.Ho, g.Wo, Co), (dy.shape, (B, g.Ho, g.Wo, Co))
+    if (kind == "c3up" and PHASE_UPCONV and PRECISION == PREC_F32 and xf == XF_NONE and x16 is None
+            and _upconv_phase_wgrad(dy, x, gv, bgrad_out)):
+        return
     npix = B * g.Ho * g.Wo
     a = WgradArgs()
     a.dY, a.X = _p(dy), _p(x)
