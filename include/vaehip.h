@@ -106,7 +106,7 @@ int vae_igemm_rows(const vae_igemm_args* a, void* stream);
 /* number of chunks per image the launch for `a` (with a->gstat_groups set) would write into a->gstat, or 0 when the
  * kernel serving it has no statistics epilogue (the caller then runs vae_gn_stats_partial on the output)           */
 int vae_conv_gstat_chunks(const vae_igemm_args* a);
-/* 1 when the kernel that would serve `a` honours tapmask / a_step.. / c_step.. (the fp32 halo-tile kernel), else 0  */
+/* 1 when the kernel that would serve `a` honours tapmask / a_step.. / c_step.. (the halo-tile kernels), else 0     */
 int vae_conv_phase_ok(const vae_igemm_args* a);
 /* W [Co][3][3][Ci] (OHWI) -> Weff [4 phases (a*2+b)][Co][3][3][Ci]: the 3x3 kernel each output parity (a,b) of
  * conv3x3(nearest_upsample_2x(x)) applies to the LOW-resolution x (zeros outside its 2x2 support; sums of 1, 2 or 4

@@ -579,3 +579,34 @@ def test_upconv_phase_decomposition(cuda):
     assert _rel(_nchw(dx), xr.grad) < 2e-5
     assert _rel(gw.cpu(), wr.grad) < 3e-5
     assert _rel(gb.cpu(), dy.sum(dim=(0, 2, 3))) < 3e-5
+
+
+def test_bf16_upconv_phase_decomposition(cuda, bf16_mode, packed_weights):
+    """bf16 mode: the upsampler's forward and dgrad as four phase convolutions; the effective kernels (sums of fp32 taps) are
+    rounded to bf16 once, so the reference rounds the SUMS, not the taps."""
+    from vaehip import ops
+    gen = torch.Generator().manual_seed(78)
+    B, H, W, Ci, Co = 2, 4, 32, 128, 128
+    x = torch.randn(B, Ci, H, W, generator=gen)
+    w = torch.randn(Co, Ci, 3, 3, generator=gen) / math.sqrt(9 * Ci)
+    wd = packed_weights(_to_dev_ohwi(w))
+    we = ops.upconv_phase_weights(wd.permute(0, 2, 3, 1)).cpu()
+    prof = ops.PROFILER = ops.LaunchProfiler()
+    try:
+        y = ops.conv_fwd(_nhwc(x), wd, None, "c3up")
+        dy = torch.randn(B, Co, 2 * H, 2 * W, generator=gen)
+        dx = ops.conv_dgrad(_nhwc(dy), wd, "c3up", (H, W))
+    finally:
+        ops.PROFILER = None
+    assert len(prof.records) == 8 and all(r[0].startswith("conv3_tile_bf16_kernel") for r in prof.records), [r[0] for r in prof.records]
+    y_ref = torch.zeros(B, Co, 2 * H, 2 * W)
+    xr = _r16(x).requires_grad_(True)
+    for pa in (0, 1):
+        for pb in (0, 1):
+            y_ref[:, :, pa::2, pb::2] = F.conv2d(xr, _r16(we[pa * 2 + pb].permute(0, 3, 1, 2)), None, 1, 1)
+    assert _rel(_nchw(y), y_ref.detach()) < 2e-5
+    (gx,) = torch.autograd.grad(sum(F.conv2d(xr, _r16(we[pa * 2 + pb].permute(0, 3, 1, 2)), None, 1, 1).mul(_r16(dy)[:, :, pa::2, pb::2]).sum()
+                                    for pa in (0, 1) for pb in (0, 1)), xr)
+    assert _rel(_nchw(dx), gx) < 2e-5
+    # and close to the fp32 upsample + conv at bf16 accuracy
+    assert _rel(_nchw(y), F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, None, 1, 1)) < 2e-2

@@ -54,7 +54,16 @@ __global__ __launch_bounds__(NT, 2) void conv3_tile_bf16_kernel(vae_igemm_args p
   const vae_conv_geom g = p.g;
   const int tilesN = (p.N + BN - 1) / BN;
   // operand streams through buffer descriptors (common.h); the activation descriptor is made per tile (one image)
-  const size_t img_bytes = (size_t)g.Hs * g.Ws * g.Cs * 4u;
+  // sub-sampled views and tap subsets (phase convolutions of an upsampler, vaehip.h): pixel (y,x) of A is (y*as+a_oy, x*as+a_ox)
+  // of a tensor `as` times larger, likewise C / res with cs; masked kernel rows skip their MFMA step, masked columns their groups
+  // (only the instantiation without an input transform carries this: the upsamplers have no GroupNorm in front)
+  constexpr bool PHASE = (XF == VAE_XF_NONE) && !A16;
+  const int as = (PHASE && p.a_step > 1) ? p.a_step : 1, cs = (PHASE && p.c_step > 1) ? p.c_step : 1;
+  const int tmask = (PHASE && p.tapmask) ? p.tapmask : 0x1ff;
+  const int rmask = ((tmask & 7) ? 1 : 0) | (((tmask >> 3) & 7) ? 2 : 0) | (((tmask >> 6) & 7) ? 4 : 0);
+  const int cmask = (tmask | (tmask >> 3) | (tmask >> 6)) & 7;
+  const int kw0 = (cmask & 1) ? 0 : 1, ngrp = 2 * __builtin_popcount(cmask);  // active columns kw0.., 2 k-groups each
+  const size_t img_bytes = (size_t)(g.Hs * as) * (g.Ws * as) * g.Cs * 4u;
   const auto rsW = VAE_BUF_RSRC(p.Wh, (size_t)(DG ? p.K * p.sk : p.N * p.sn) * 2u);
   const int Hb = UP ? 2 * g.Hs : g.Hs, Wb = UP ? 2 * g.Ws : g.Ws;
   const int kchunks = (p.K + BK - 1) / BK;
@@ -119,7 +128,7 @@ __global__ __launch_bounds__(NT, 2) void conv3_tile_bf16_kernel(vae_igemm_args p
     }
     hmask = 0;
     const int c = c0 + hk4 * 4;
-    const auto rsA = VAE_BUF_RSRC(p.A + (int64_t)id.b * g.Hs * g.Ws * g.Cs, img_bytes);
+    const auto rsA = VAE_BUF_RSRC(p.A + (int64_t)id.b * (g.Hs * as) * (g.Ws * as) * g.Cs, img_bytes);
     if (XF != VAE_XF_NONE) {
       const int cs = min(c, p.K - 4);
       rsc = *reinterpret_cast<const f32x4*>(p.scale + (int64_t)id.b * g.Cs + cs);
@@ -133,7 +142,7 @@ __global__ __launch_bounds__(NT, 2) void conv3_tile_bf16_kernel(vae_igemm_args p
       const int hy = id.y0 - 1 + ir, hx = id.x0 - 1 + jc;
       const bool ok = (q < HQ) && ((unsigned)hy < Hv) && ((unsigned)hx < (unsigned)Wb) && (c < p.K);
       const int sy = UP ? (hy >> 1) : hy, sx = UP ? (hx >> 1) : hx;
-      rh[i] = VAE_BUF_LOAD4(rsA, ok ? (unsigned)(((sy * g.Ws + sx) * g.Cs + c) * 4) : BUF_OOB);
+      rh[i] = VAE_BUF_LOAD4(rsA, ok ? (unsigned)((((sy * as + (PHASE ? p.a_oy : 0)) * (g.Ws * as) + sx * as + (PHASE ? p.a_ox : 0)) * g.Cs + c) * 4) : BUF_OOB);
       hmask |= (ok ? 1 : 0) << i;
     }
   };
@@ -211,12 +220,16 @@ __global__ __launch_bounds__(NT, 2) void conv3_tile_bf16_kernel(vae_igemm_args p
   // one step: 6 MFMA groups (3 taps x 2 k-groups of 16 channels), each 2 pixel-row x 2 channel-block fragments and
   // 4 MFMAs; the fragments of group i+1 are requested before the MFMAs of group i are issued
   auto compute = [&](auto with_xform, int kh, const u16* sB) {
+    if (PHASE && !((rmask >> kh) & 1)) {  // uniform: a kernel row outside the tap mask
+      if (decltype(with_xform)::value) xform_halo();
+      return;
+    }
     const int dy = DG ? 2 - kh : kh;
     const u16* aBase = sH + ((2 * wm + dy) * HW_ + lr) * LDH + lh * 8;
     const u16* bBase = DG ? sB + (lh * 8 + trq) * LDB + wn * 64 + trh * 16 + trp * 4 : sB + (wn * 64 + lr) * LDB + lh * 8;
     bf16x8 fa[2][2], fb[2][2];
     auto fetch = [&](int grp, bf16x8* a, bf16x8* b) {
-      const int kw = grp >> 1, kg = grp & 1;
+      const int kw = kw0 + (grp >> 1), kg = grp & 1;
       const int dx = DG ? 2 - kw : kw;
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) a[mi] = frag_direct(aBase + (mi * HW_ + dx) * LDH + kg * 16);
@@ -229,13 +242,15 @@ __global__ __launch_bounds__(NT, 2) void conv3_tile_bf16_kernel(vae_igemm_args p
     fetch(0, fa[0], fb[0]);
 #pragma unroll
     for (int grp = 0; grp < 6; ++grp) {
-      if (grp + 1 < 6) fetch(grp + 1, fa[(grp + 1) & 1], fb[(grp + 1) & 1]);
+      if (grp + 1 < ngrp) fetch(grp + 1, fa[(grp + 1) & 1], fb[(grp + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);  // hipcc otherwise sinks each read to just before its MFMA and waits for it there
+      if (grp < ngrp) {  // uniform (4 groups when a kernel column is masked)
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[grp & 1][mi], fb[grp & 1][ni], acc[mi][ni], 0, 0, 0);
+          for (int ni = 0; ni < 2; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[grp & 1][mi], fb[grp & 1][ni], acc[mi][ni], 0, 0, 0);
+      }
       if (decltype(with_xform)::value) {  // the next chunk's halo, transformed under this group's MFMAs
         static_assert(HI <= 12, "two halo slots per MFMA group at most");
         if (grp < HI) xform_slot(grp);
@@ -299,9 +314,9 @@ __global__ __launch_bounds__(NT, 2) void conv3_tile_bf16_kernel(vae_igemm_args p
     // outputs and the residual go through buffer descriptors over this tile's image: a pixel / channel outside the
     // tensor is an out-of-range offset (load reads 0, store is dropped), so the 16 residual loads of a block are issued
     // back to back and there is no branch per element
-    const size_t obytes = (size_t)g.Ho * g.Wo * p.ldc * 4u;
-    const auto rsC = VAE_BUF_RSRC(p.C + (int64_t)cur.b * g.Ho * g.Wo * p.ldc, obytes);
-    const auto rsR = VAE_BUF_RSRC((p.res ? p.res : p.C) + (int64_t)cur.b * g.Ho * g.Wo * p.ldc, obytes);
+    const size_t obytes = (size_t)(g.Ho * cs) * (g.Wo * cs) * p.ldc * 4u;
+    const auto rsC = VAE_BUF_RSRC(p.C + (int64_t)cur.b * (g.Ho * cs) * (g.Wo * cs) * p.ldc, obytes);
+    const auto rsR = VAE_BUF_RSRC((p.res ? p.res : p.C) + (int64_t)cur.b * (g.Ho * cs) * (g.Wo * cs) * p.ldc, obytes);
     float tsum[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, gs1[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, gs2[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
@@ -316,7 +331,7 @@ __global__ __launch_bounds__(NT, 2) void conv3_tile_bf16_kernel(vae_igemm_args p
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int ox = cur.x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          off[r] = (colok && ox < g.Wo) ? (unsigned)(((oy * g.Wo + ox) * p.ldc + col) * 4) : BUF_OOB;
+          off[r] = (colok && ox < g.Wo) ? (unsigned)((((oy * cs + (PHASE ? p.c_oy : 0)) * (g.Wo * cs) + ox * cs + (PHASE ? p.c_ox : 0)) * p.ldc + col) * 4) : BUF_OOB;
           rv[r] = 0.f;
         }
         if (p.res) {  // uniform
@@ -408,7 +423,8 @@ void launch_xf(const vae_igemm_args& a, dim3 grid, int tx, int ty, int nt, hipSt
 // straddle a row end
 bool conv3_tile_bf16_packed(const vae_igemm_args& a) {
   const vae_conv_geom& g = a.g;
-  const bool fits32 = (size_t)g.Hs * g.Ws * g.Cs * 4u < BUF_MAX && (size_t)g.Ho * g.Wo * a.ldc * 4u < BUF_MAX &&  // one image per descriptor
+  const size_t as = a.a_step > 1 ? a.a_step : 1, cs = a.c_step > 1 ? a.c_step : 1;
+  const bool fits32 = (size_t)g.Hs * g.Ws * g.Cs * 4u * as * as < BUF_MAX && (size_t)g.Ho * g.Wo * a.ldc * 4u * cs * cs < BUF_MAX &&  // one image per descriptor
                       (size_t)std::max((int64_t)a.K * a.sk, (int64_t)a.N * a.sn) * 2u < BUF_MAX;
   return a.Wh != nullptr && aligned16(a.Wh) && aligned16(a.A) && fits32 && a.K % 8 == 0 && a.N % 8 == 0 && a.st % 8 == 0 &&
          (a.sn == 1 || a.sn % 8 == 0) && (a.sk == 1 || a.sk % 8 == 0);

@@ -707,7 +707,9 @@ extern "C" int vae_conv_phase_ok(const vae_igemm_args* ap) {
   if (!ap) return 0;
   const vae_igemm_args& a = *ap;
   const bool bkm = rows_bkm(a), vec = rows_vec(a, bkm);
-  return (a.prec != VAE_PREC_BF16 && a.A16 == nullptr && rows_use_tile(a, vec, bkm)) ? 1 : 0;
+  if (a.A16 != nullptr) return 0;
+  if (a.prec == VAE_PREC_BF16) return (a.xf == VAE_XF_NONE && rows_use_tile_bf16(a, vec, bkm)) ? 1 : 0;  // no transform variant there
+  return rows_use_tile(a, vec, bkm) ? 1 : 0;
 }
 extern "C" int vae_conv_gstat_chunks(const vae_igemm_args* ap) {
   if (!ap) return 0;
@@ -725,7 +727,9 @@ extern "C" int vae_igemm_kernel_name(const vae_igemm_args* ap, char* buf, int32_
   const vae_igemm_args& a = *ap;
   const bool bkm = rows_bkm(a), vec = rows_vec(a, bkm);
   const char* tf[2] = {"false", "true"};
-  if (rows_is_phase(a))
+  if (rows_is_phase(a) && a.prec == VAE_PREC_BF16)
+    snprintf(buf, n, "conv3_tile_bf16_kernel<%s,%s,%d,false>", tf[a.g.mode == VAE_MODE_DGRAD], tf[a.g.mode == VAE_MODE_UP2X], a.xf);
+  else if (rows_is_phase(a))
     snprintf(buf, n, "conv3_tile_kernel<%s,%s,%s,%d>", tf[bkm], tf[a.g.mode == VAE_MODE_DGRAD], tf[a.g.mode == VAE_MODE_UP2X], a.xf);
   else if (conv_smallk_eligible(a))
     snprintf(buf, n, "conv_smallk_kernel");
@@ -780,9 +784,9 @@ extern "C" int vae_igemm_rows(const vae_igemm_args* ap, void* stream) {
   VAE_CHECK(a.gstat == nullptr || vae_conv_gstat_chunks(ap) > 0, "igemm_rows: no statistics epilogue for these arguments (vae_conv_gstat_chunks)");
   hipStream_t st = (hipStream_t)stream;
   if (rows_is_phase(a)) {  // sub-sampled views / tap subsets: only the fp32 halo-tile kernel implements them
-    VAE_CHECK(vae_conv_phase_ok(ap), "igemm_rows: tapmask / a_step / c_step need the fp32 halo-tile kernel (vae_conv_phase_ok)");
+    VAE_CHECK(vae_conv_phase_ok(ap), "igemm_rows: tapmask / a_step / c_step need a halo-tile kernel (vae_conv_phase_ok)");
     VAE_CHECK(a.track == nullptr && a.gstat == nullptr, "igemm_rows: no tracker / statistics epilogue on a sub-sampled output");
-    if (int rc2 = launch_conv3_tile(a, bkm, st)) return rc2;
+    if (int rc2 = (a.prec == VAE_PREC_BF16) ? launch_conv3_tile_bf16(a, bkm, st) : launch_conv3_tile(a, bkm, st)) return rc2;
     VAE_LAUNCH_CHECK("conv3_tile");
     return VAE_OK;
   }

@@ -221,8 +221,23 @@ def _phase_args(x_lo_shape, Co, Ci, dgrad: bool) -> IgemmArgs:
         a.M, a.N, a.K, a.ldc = B * H * W, Ci, Co, Ci
         a.sn, a.sk, a.st = 1, 9 * Ci, Ci
     a.batch, a.sAb, a.sWb, a.sCb = 1, 0, 0, 0
-    a.xf, a.alpha, a.prec = XF_NONE, 1.0, PREC_F32
+    a.xf, a.alpha, a.prec = XF_NONE, 1.0, PRECISION
     return a
+
+
+def _phase_weight_ptrs(a: IgemmArgs, we: torch.Tensor, ph: int, we16: Optional[torch.Tensor]):
+    a.W = _p(we[ph])
+    a.Wh = _p(we16[ph]) if we16 is not None else None
+
+
+def _phase_weights(wv):
+    """effective kernels of the four phases, and their bf16 image in bf16 mode"""
+    we = upconv_phase_weights(wv)
+    we16 = None
+    if PRECISION == PREC_BF16:
+        we16 = torch.empty(we.shape, device=we.device, dtype=torch.bfloat16)
+        pack_bf16(we, we16)
+    return we, we16
 
 
 def _upconv_phase_fwd(x, wv, bias):
@@ -236,12 +251,13 @@ def _upconv_phase_fwd(x, wv, bias):
     out = torch.empty((B, 2 * H, 2 * W, Co), device=x.device, dtype=torch.float32)
     a.C, a.bias = _p(out), _p(bias)
     a.c_step = 2
+    a.Wh = _wh(wv)  # (eligibility of the bf16 kernel: any aligned image will do for the query)
     if not lib.query("vae_conv_phase_ok", C.byref(a)):
         return None
-    we = upconv_phase_weights(wv)
+    we, we16 = _phase_weights(wv)
     for pa in (0, 1):
         for pb in (0, 1):
-            a.W = _p(we[pa * 2 + pb])
+            _phase_weight_ptrs(a, we, pa * 2 + pb, we16)
             a.tapmask, a.c_oy, a.c_ox = _phase_tapmask(pa, pb), pa, pb
             _launch_igemm(a)
     return out
@@ -257,13 +273,14 @@ def _upconv_phase_dgrad(dy, wv, in_hw):
     out = torch.empty((B, H, W, Ci), device=dy.device, dtype=torch.float32)
     a.C = _p(out)
     a.a_step = 2
+    a.Wh = _wh(wv)
     if not lib.query("vae_conv_phase_ok", C.byref(a)):
         return None
-    we = upconv_phase_weights(wv)
+    we, we16 = _phase_weights(wv)
     first = True
     for pa in (0, 1):
         for pb in (0, 1):
-            a.W = _p(we[pa * 2 + pb])
+            _phase_weight_ptrs(a, we, pa * 2 + pb, we16)
             a.tapmask, a.a_oy, a.a_ox = _phase_tapmask(pa, pb), pa, pb
             a.res = None if first else _p(out)  # the four phases add up
             _launch_igemm(a)
@@ -283,8 +300,7 @@ def conv_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], kin
     if a16 is not None:
         assert a16.shape == x.shape and a16.dtype == torch.bfloat16 and a16.is_contiguous()
         xf = XF_NONE
-    if (kind == "c3up" and PHASE_UPCONV and PRECISION == PREC_F32 and xf == XF_NONE and res is None and track is None
-            and a16 is None):
+    if kind == "c3up" and PHASE_UPCONV and xf == XF_NONE and res is None and track is None and a16 is None:
         out = _upconv_phase_fwd(x, ohwi(w), bias)
         if out is not None:
             return out
@@ -333,7 +349,7 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, kind: str, in_hw: Tuple[int, i
     B, Hy, Wy, Cy = dy.shape
     assert Cy == Co
     H, W = in_hw
-    if kind == "c3up" and PHASE_UPCONV and PRECISION == PREC_F32:
+    if kind == "c3up" and PHASE_UPCONV:
         out = _upconv_phase_dgrad(dy, wv, in_hw)
         if out is not None:
             return out
