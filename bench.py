@@ -208,6 +208,7 @@ def main():
                                    f"random-init weights (synthetic:42)",
                        "global_batch": world * B, "resolution": R, "parallelism": f"dp{world}"},
             "loss": {"mse": sc[0], "kl": sc[1], "total": sc[2]},
+            "peak_hbm_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
             "roofline": roof, "hbm_step": hbm, "cpu_baseline": cpu, "kernels": kernels,
         }
         print(json.dumps(line))
