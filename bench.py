@@ -40,9 +40,10 @@ CLASSIFY_CFG = {
 }
 
 
-def cpu_baseline(max_seconds: float = 40.0):
-    """reference-equivalent CPU path (PyTorch oracle) on the host cores: one full train step
-    (fwd+loss+bwd+clip+AdamW, 3 tracker hooks) on a bounded sample of the same workload."""
+def cpu_baseline(budget_s: float = 15.0):
+    """reference-equivalent CPU path (PyTorch oracle) on the host cores: full train steps (fwd+loss+bwd+clip+AdamW,
+    3 tracker hooks) on a bounded sample of the same workload.  One step at batch 1 warms the libraries up at the full
+    resolution and sizes the sample: the largest batch <= the config's 16 whose step fits `budget_s`, then 2 timed steps."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import vae_oracle as vo
     cores = torch.get_num_threads()
@@ -54,23 +55,56 @@ def cpu_baseline(max_seconds: float = 40.0):
             vo.mean_abs_per_channel(out)
         hooks.append(mod.register_forward_hook(hook))
     tr = vo.OracleTrainer(o, max_steps=100)
-    tr.step(vo.synthetic_pixels(1, 64, 1), vo.synthetic_eps(1, 64, 1))  # warm-up (library init)
-    b = 1
-    x, e = vo.synthetic_pixels(b, RES, 42), vo.synthetic_eps(b, RES, 42)
     t0 = time.perf_counter()
-    tr.step(x, e)
-    dt = time.perf_counter() - t0
-    steps = 1
-    while dt < 10.0 and steps < 4:
-        t1 = time.perf_counter()
+    tr.step(vo.synthetic_pixels(1, RES, 41), vo.synthetic_eps(1, RES, 41))  # warm-up at full resolution, untimed
+    t1 = time.perf_counter() - t0
+    b = int(max(1, min(BATCH_PER_GPU, budget_s // max(t1, 1e-3))))
+    x, e = vo.synthetic_pixels(b, RES, 42), vo.synthetic_eps(b, RES, 42)
+    times = []
+    for _ in range(2):
+        t0 = time.perf_counter()
         tr.step(x, e)
-        dt += time.perf_counter() - t1
-        steps += 1
+        times.append(time.perf_counter() - t0)
     for h in hooks:
         h.remove()
-    return {"value": round(b * steps / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"{steps} full train step(s) at batch {b}, 256x256, fp32, torch CPU ({cores} threads); "
-                      f"oracle = plain-PyTorch restatement of the reference diffusers path"}
+    dt = sum(times)
+    return {"value": round(b * len(times) / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "step_seconds": [round(t, 2) for t in times], "warmup_step_seconds_batch1": round(t1, 2),
+            "sample": f"{len(times)} timed full train steps at batch {b} (largest batch <= {BATCH_PER_GPU} whose step fits "
+                      f"{budget_s:.0f} s; config batch is {BATCH_PER_GPU}) after one untimed step, 256x256, fp32, torch CPU "
+                      f"({cores} threads); oracle = plain-PyTorch restatement of the reference diffusers path"}
+
+
+def _free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n: int) -> int:
+    """`bench.py --gpus N` without a launcher: start N ranks of this script through torch.distributed.run (one process
+    per GPU, 127.0.0.1 rendezvous) BEFORE this process touches the GPU, pass their output through and return the exit
+    code.  Rank 0 of the children prints the JSON line."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver supports dmabuf IPC only (RCCL needs it)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def workload_label(dtype: str, R: int, B: int, ckpt: bool, nudge: int, tracking: bool) -> str:
+    """which BASELINE.json config this run is (by shape), in words"""
+    if dtype == "f32":
+        idx = 1 if (R == 256 and B == 16) else None
+    else:
+        idx = {256: 2, 512: 3, 1024: 4}.get(R)
+    head = f"BASELINE configs[{idx}]" if idx is not None else "off-baseline shape"
+    prec = "fp32" if dtype == "f32" else "bf16 MFMA compute (fp32 accumulate, fp32 master weights and statistics)"
+    extra = (", decoder activation-checkpointed" if ckpt else "") + (f", gentle nudge every {nudge} steps" if nudge else ", no nudge")
+    return (f"{head}: SDXL-VAE {R}x{R} synthetic RGB, batch {B}/GPU, {prec}, "
+            f"tracking {'on (3 layers) + classifier' if tracking else 'off'}{extra}; random-init weights (synthetic:42)")
 
 
 def main():
@@ -85,6 +119,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tracking", action="store_true", help="A/B switch for the tracker-overhead measurement")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP-event timing")
+    ap.add_argument("--nudge-interval", type=int, default=0,
+                    help="InterventionHandler (gentle nudge x1.10, cap 1.5) every K steps inside the timed loop (BASELINE configs[3]: 100)")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl", help="nccl = RCCL over xGMI (the product path)")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="launch the ranks, form the process group, all-reduce one number and print it: the multi-rank "
+                         "plumbing without touching a GPU (CPU test of the launcher, with --dist-backend gloo)")
     ap.add_argument("--checkpoint-decoder", action="store_true",
                     help="training.gradient_checkpointing: decoder (BASELINE configs[4], 1024x1024): decoder segments keep only their inputs")
     args = ap.parse_args()
@@ -92,13 +132,29 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus))  # nothing has touched the GPU in this process
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if args.rendezvous_only:
+        dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+        t = torch.tensor([float(rank + 1)])
+        if args.dist_backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            t = t.cuda()
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"rendezvous": "ok", "world": dist.get_world_size(), "backend": dist.get_backend(),
+                              "allreduce_sum": float(t.item())}))
+        dist.destroy_process_group()
+        return
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from models.sdxl_vae_wrapper import SDXLVAEWrapper
     from tracking.monitor import ActivityMonitor
@@ -110,9 +166,18 @@ def main():
     w = SDXLVAEWrapper("synthetic:42", device=dev)
     trainer = HipTrainer(w, lr=1e-5, max_grad_norm=1.0, kl_weight=1e-6, lr_warmup_steps=100,
                          max_train_steps=10000, scheduler_steps_per_update=world,
-                         mixed_precision="bf16" if args.dtype == "bf16" else "no", checkpoint_decoder=args.checkpoint_decoder)
+                         mixed_precision="bf16" if args.dtype == "bf16" else "no", checkpoint_decoder=args.checkpoint_decoder,
+                         time_comm=world > 1)
     monitor = None if args.no_tracking else ActivityMonitor(w, TRACKING_CFG)
     classifier = None if args.no_tracking else RegionClassifier(w.vae, CLASSIFY_CFG)
+    nudger = None
+    if args.nudge_interval > 0 and not args.no_tracking:
+        from intervention.nudger import InterventionHandler
+        nudger = InterventionHandler(w.vae, {"enabled": True, "strategy": "gentle_nudge_gn_scale", "nudge_factor": 1.10,
+                                             "max_scale_value": 1.5, "intervention_interval": args.nudge_interval})
+    track_interval = TRACKING_CFG["track_interval"] if not nudger else min(TRACKING_CFG["track_interval"], args.nudge_interval)
+    if monitor is not None:
+        monitor.config["track_interval"] = track_interval
 
     gen = torch.Generator(device=dev).manual_seed(42 + rank)
     B, R = args.batch, args.res
@@ -121,11 +186,13 @@ def main():
 
     def one_step():
         trainer.train_step(x, eps)
-        if monitor is not None and trainer.global_step % TRACKING_CFG["track_interval"] == 0:
+        if monitor is not None and trainer.global_step % track_interval == 0:
             monitor.step(trainer.global_step)
             data = monitor.get_data_for_step(trainer.global_step)
             if data:
-                classifier.classify(data, trainer.global_step)
+                found = classifier.classify(data, trainer.global_step)
+                if nudger is not None and found and trainer.global_step % args.nudge_interval == 0:
+                    nudger.intervene(found, trainer.global_step)  # every rank applies the same nudge to the live arena
 
     for _ in range(args.warmup):
         one_step()
@@ -149,6 +216,15 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
     sc = trainer.last["scalars"].cpu().tolist()
+    comm = None
+    if world > 1:
+        ex = torch.tensor([trainer.exposed_comm_ms() / max(args.steps, 1)], device=dev, dtype=torch.float64)
+        dist.all_reduce(ex, op=dist.ReduceOp.MAX)
+        comm = {"world_size": dist.get_world_size(), "backend": dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else ""),
+                "gradient_bytes_per_step": int(w.vae.arena.grad.numel()) * 4, "bucket_mb": trainer.bucket_mb,
+                "buckets": len(trainer.reducer.buckets) if trainer.reducer is not None else 0,
+                "exposed_ms_per_step_max_over_ranks": round(float(ex.item()), 3),
+                "note": "exposed = time the compute stream waits in reducer.finish() for all-reduces the backward pass did not hide"}
 
     if rank == 0:
         roof = None
@@ -197,19 +273,16 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline()
         line = {
-            "metric": "images/sec SDXL-VAE train step @256x256 (tracking on)",
+            "metric": f"images/sec SDXL-VAE train step @{R}x{R} (tracking {'off' if args.no_tracking else 'on'})",
             "value": round(world * B * args.steps / dt, 3), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[{1 if args.dtype == 'f32' else 2}]: SDXL-VAE {R}x{R} synthetic RGB, batch {B}/GPU, "
-                                   f"{'fp32' if args.dtype == 'f32' else 'bf16 MFMA compute (fp32 accumulate, fp32 tensors/master weights)'}, "
-                                   f"tracking {'off' if args.no_tracking else 'on (3 layers) + classifier'}, no nudge; "
-                                   f"random-init weights (synthetic:42)",
+            "config": {"workload": workload_label(args.dtype, R, B, args.checkpoint_decoder, args.nudge_interval if nudger else 0, not args.no_tracking),
                        "global_batch": world * B, "resolution": R, "parallelism": f"dp{world}"},
             "loss": {"mse": sc[0], "kl": sc[1], "total": sc[2]},
             "peak_hbm_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
-            "roofline": roof, "hbm_step": hbm, "cpu_baseline": cpu, "kernels": kernels,
+            "roofline": roof, "hbm_step": hbm, "cpu_baseline": cpu, "comm": comm, "kernels": kernels,
         }
         print(json.dumps(line))
     if world > 1:

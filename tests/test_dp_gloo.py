@@ -66,3 +66,58 @@ def test_bucketed_gradient_mean_world2():
         assert la == []                       # nothing final yet: the top bucket starts at 5904 < 9000
         assert lb == [(5904, 10000)]          # [1808,5904) is not final at watermark 4097
         assert sc == pytest.approx([0.5, 1.0, 1.0])
+
+
+def _accum_worker(rank, world, port, q):
+    """HipTrainer's accumulated update across ranks with the device kernels replaced by host stand-ins: the sum of the
+    earlier micro-batches is all-reduced from the start of the due micro-batch, that micro-batch's own gradient through
+    the watermark reducer, and the two means add up to the mean over ranks of the window's sum."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from models.sdxl_vae_wrapper import SDXLVAEWrapper
+        from vaehip.trainer import HipTrainer
+        w = SDXLVAEWrapper("synthetic:%d" % (rank + 1))  # replicas start different: the trainer broadcasts rank 0's
+        tr = HipTrainer(w, lr=1.0, lr_warmup_steps=0, max_train_steps=10, gradient_accumulation_steps=3, bucket_mb=64.0,
+                        time_comm=True)
+        chk = float(w.vae.arena.flat.double().sum())
+        grad = w.vae.arena.grad
+        eng = w.vae.engine
+        seen = []
+
+        def fake_fwd_bwd(pv, eps, klw, sample, gen, grad_scale=1.0):
+            grad.fill_(float(pv) * grad_scale)
+            if eng.reducer is not None:   # what the tape does: watermarks from the top of the arena down
+                eng.reducer.ready(grad.numel() // 2)
+                eng.reducer.ready(0)
+            return {"scalars": torch.zeros(3)}
+        eng.forward_backward = fake_fwd_bwd
+        tr._add = lambda a, b, out: torch.add(a, b, out=out)
+        tr.optimizer.step = lambda: seen.append((float(grad[0]), float(grad[-1]), float(grad.min()), float(grad.max())))
+        vals = [[3.0, 6.0, 9.0, 12.0], [30.0, 60.0, 90.0, 120.0]][rank]
+        tr.train_step(vals[0]); tr.train_step(vals[1]); tr.train_step(vals[2])       # full window
+        tr.train_step(vals[3], end_of_dataloader=True)                                # partial window of one
+        q.put((rank, chk, seen, tr.global_step, tr.exposed_comm_ms() >= 0.0))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_accumulated_update_exchange_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_accum_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, c0, s0, g0, t0), (_, c1, s1, g1, t1) = out
+    assert c0 == c1                                   # parameters broadcast from rank 0
+    assert g0 == g1 == 2 and t0 and t1
+    want1 = ((3 + 6 + 9) / 3 + (30 + 60 + 90) / 3) / 2  # mean over ranks of the window's 1/N-scaled sum
+    want2 = (12 / 3 + 120 / 3) / 2
+    for s in (s0, s1):
+        assert s[0] == pytest.approx((want1,) * 4) and s[1] == pytest.approx((want2,) * 4)

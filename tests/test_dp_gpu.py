@@ -1,5 +1,7 @@
-"""Data-parallel train step on the GPU with the real engine: 2 ranks (both on cuda:0, gloo backend --
-RCCL refuses two ranks on one device; the 8-GPU RCCL run is the driver's).  Checks that the bucketed
+"""Data-parallel train step on the GPU with the real engine: 2 ranks.  On a one-GPU box both ranks sit on cuda:0 with
+the gloo backend (RCCL refuses two ranks on one device); where two devices are visible the same scenario also runs on
+"nccl" (= RCCL), one device per rank: ReduceOp.AVG, async collectives on RCCL's stream against kernels launched through
+the raw stream pointer, and the stream wait before the norm / AdamW kernels.  Checks that the bucketed
 all-reduce driven by the backward watermarks produces exactly the single-process result for the
 mean gradient, that replicas stay identical, and that tracker vectors are averaged across ranks."""
 import os
@@ -20,20 +22,24 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, q, accum=1):
+def _worker(rank, world, port, q, accum=1, backend="gloo"):
     import sys
     for p in (os.path.join(ROOT, "vae-channel-dynamics_amd", "src"), os.path.join(ROOT, "oracle")):
         if p not in sys.path:
             sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    devno = rank if backend == "nccl" else 0
+    torch.cuda.set_device(devno)  # before any other GPU call
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", devno))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import vae_oracle as vo
         from models.sdxl_vae_wrapper import SDXLVAEWrapper
         from tracking.monitor import ActivityMonitor
         from vaehip.trainer import HipTrainer
-        dev = torch.device("cuda:0")
+        dev = torch.device("cuda", devno)
         w = SDXLVAEWrapper("synthetic:7", device=dev)
         if rank == 1:  # replicas start different: the trainer must broadcast rank 0's parameters
             with torch.no_grad():
@@ -84,13 +90,15 @@ def _worker(rank, world, port, q, accum=1):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("accum", [1, 2])
-def test_two_rank_step_equals_mean_gradient_step(cuda, accum):
+@pytest.mark.parametrize("accum,backend", [(1, "gloo"), (2, "gloo"), (1, "nccl"), (3, "nccl")])
+def test_two_rank_step_equals_mean_gradient_step(cuda, accum, backend):
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("RCCL needs one device per rank; this box has one GPU (the driver's multi-GPU bench covers nccl)")
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, accum)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, accum, backend)) for r in range(world)]
     for p in procs:
         p.start()
     out = sorted(q.get(timeout=600) for _ in range(world))

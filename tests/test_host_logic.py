@@ -211,3 +211,41 @@ def test_lr_schedule_and_data_pipeline(tmp_path):
     g = ds2[1]["pixel_values"]
     assert torch.allclose(g, torch.full_like(g, 128 / 255 * 2 - 1), atol=1e-6)
     assert get_transform(8)(Image.new("RGB", (8, 8), (255, 0, 0)))[0].min() == 1.0
+
+
+def test_accumulation_window_is_flushed_at_the_end_of_a_dataloader_pass():
+    """accelerate.accumulate forces an optimizer update on the last batch of every dataloader pass (accelerator.py
+    _do_sync), so ceil(len/accum) updates happen per epoch -- the count train.py:188-195 schedules.  Host logic only:
+    the engine, the add kernel and the optimizer kernels are replaced by stand-ins (they need a GPU)."""
+    import math
+    from models.sdxl_vae_wrapper import SDXLVAEWrapper
+    from train import with_last
+    from vaehip.trainer import HipTrainer
+    assert list(with_last([])) == [] and list(with_last("abc")) == [("a", False), ("b", False), ("c", True)]
+    w = SDXLVAEWrapper("synthetic:1")
+    n_batches, accum, epochs = 5, 2, 3
+    upd_per_epoch = math.ceil(n_batches / accum)
+    tr = HipTrainer(w, lr=1.0, lr_warmup_steps=0, max_train_steps=epochs * upd_per_epoch, gradient_accumulation_steps=accum)
+    grad = w.vae.arena.grad
+    seen = []  # gradient sums the optimizer saw
+
+    def fake_fwd_bwd(pv, eps, klw, sample, gen, grad_scale=1.0):
+        grad.fill_(float(pv) * grad_scale)
+        return {"scalars": torch.zeros(3)}
+    w.vae.engine.forward_backward = fake_fwd_bwd
+    tr._add = lambda a, b, out: torch.add(a, b, out=out)
+    tr.optimizer.step = lambda: seen.append(float(grad[0]))
+    updates = 0
+    for _ in range(epochs):
+        for b, last in with_last(range(1, n_batches + 1)):
+            tr.train_step(b, None, end_of_dataloader=last)
+            updates += tr.sync_gradients
+        assert tr.pending_micro_batches == 0  # nothing carries into the next epoch
+    assert updates == tr.global_step == epochs * upd_per_epoch
+    assert tr.lr_scheduler.get_last_lr()[0] == 0.0  # the LR reached the end of its linear decay
+    # windows (1,2) (3,4) (5): every micro-batch scaled by 1/accum, the partial window too
+    assert seen == [1.5, 3.5, 2.5] * epochs
+    tr.train_step(7, None)
+    assert tr.pending_micro_batches == 1
+    tr.flush()
+    assert tr.pending_micro_batches == 0 and seen[-1] == 3.5 and tr.global_step == epochs * upd_per_epoch + 1

@@ -150,6 +150,13 @@ class ActivityMonitor:
             stacked = torch.stack(values)
             if self.sync_across_ranks and torch.distributed.is_available() and torch.distributed.is_initialized() \
                     and torch.distributed.get_world_size() > 1:
+                # ranks must have buffered the same number of forwards (train.py makes them skip batches together)
+                n = torch.tensor([stacked.shape[0], -stacked.shape[0]], device=stacked.device, dtype=torch.int64)
+                torch.distributed.all_reduce(n, op=torch.distributed.ReduceOp.MAX)
+                if int(n[0]) != -int(n[1]):
+                    raise RuntimeError(f"ActivityMonitor: ranks buffered different numbers of forwards "
+                                       f"({stacked.shape[0]} here, {int(n[0])} max, {-int(n[1])} min); the per-rank "
+                                       f"tracker vectors cannot be averaged")
                 torch.distributed.all_reduce(stacked)
                 stacked = stacked / torch.distributed.get_world_size()
             host = stacked.cpu().numpy()

@@ -106,6 +106,41 @@ class MetricLogger:
             self.tb.close()
 
 
+def with_last(iterable):
+    """yields (item, is_last): accelerate's dataloader wrapper knows the end of a pass one batch ahead
+    (gradient_state.end_of_dataloader), which is what forces an optimizer update on a partial accumulation window"""
+    it = iter(iterable)
+    try:
+        prev = next(it)
+    except StopIteration:
+        return
+    for cur in it:
+        yield prev, False
+        prev = cur
+    yield prev, True
+
+
+_CTRL_GROUP = None
+
+
+def all_ranks_ok(ok: bool, world: int) -> bool:
+    """control-plane agreement on a host flag (MIN over ranks) through a gloo group: a rank whose batch failed to
+    decode must not leave its peers alone in the gradient exchange.  CPU tensors, so no device synchronisation."""
+    global _CTRL_GROUP
+    if world <= 1:
+        return ok
+    if _CTRL_GROUP is None:
+        _CTRL_GROUP = dist.new_group(backend="gloo")
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=_CTRL_GROUP)
+    return bool(flag.item())
+
+
+def valid_batch(batch) -> bool:
+    pv = batch.get("pixel_values") if batch else None  # guards the reference's None-batch crash (data_utils.py:215)
+    return pv is not None and pv.ndim == 4 and pv.shape[0] > 0
+
+
 def save_state(path: str, wrapper, trainer, rank: int = 0):
     """file layout of accelerate.save_state (accelerate/utils/constants.py:20-31) used by train.py:358-362,392-405."""
     from safetensors.torch import save_file
@@ -128,10 +163,10 @@ def run_validation(trainer: HipTrainer, val_dataloader, kl_weight: float, global
     trainer.wrapper.eval()
     sums = torch.zeros(3, device=device, dtype=torch.float64)  # rec_sum, kl_sum, samples
     for batch in val_dataloader:
-        pv = batch.get("pixel_values") if batch else None
-        if pv is None or pv.ndim != 4 or pv.shape[0] == 0:
+        if not all_ranks_ok(valid_batch(batch), world):  # every rank skips together (tracker buffers stay aligned)
             logger.warning("Validation: Invalid batch data, skipping.")
             continue
+        pv = batch["pixel_values"]
         r = trainer.eval_step(pv.to(device, dtype=torch.float32, non_blocking=True))
         sums[0] += r["rec_sum"].double()
         sums[1] += r["kl_sum"].double()
@@ -268,14 +303,20 @@ def main():
             train_dataloader.sampler.set_epoch(epoch)
         epoch_sums = torch.zeros(3, device=device, dtype=torch.float64)  # mse, kl, total (this rank)
         steps_in_epoch = 0
-        for batch in train_dataloader:
-            pv = batch.get("pixel_values") if batch else None  # guards the reference's None-batch crash (data_utils.py:215)
-            if pv is None or pv.ndim != 4 or pv.shape[0] == 0:
-                continue
-            res = trainer.train_step(pv.to(device, dtype=torch.float32, non_blocking=True))
-            sc = res["scalars"]
-            epoch_sums += sc.double()
-            steps_in_epoch += 1
+        sc = torch.zeros(3, device=device)
+        for batch, last_batch in with_last(train_dataloader):
+            if not all_ranks_ok(valid_batch(batch), world):  # all ranks skip the batch, or none does
+                if last_batch and trainer.pending_micro_batches:
+                    trainer.flush()  # the pass ends on a skipped batch: update with what has accumulated
+                else:
+                    continue
+            else:
+                pv = batch["pixel_values"]
+                # the last batch of a pass always ends in an optimizer update (accelerate.accumulate, train.py:286)
+                res = trainer.train_step(pv.to(device, dtype=torch.float32, non_blocking=True), end_of_dataloader=last_batch)
+                sc = res["scalars"]
+                epoch_sums += sc.double()
+                steps_in_epoch += 1
             if not trainer.sync_gradients:  # micro-batch of an accumulated update (train.py:286,300)
                 continue
             global_step += 1

@@ -31,8 +31,14 @@ class GradBucketReducer:
     """engine calls ready(low): every gradient at arena offset >= low is final.  Buckets whose
     whole range is final are all-reduced asynchronously; finish() waits and averages."""
 
-    def __init__(self, flat_grad: torch.Tensor, group=None, bucket_mb: float = 64.0):
+    def __init__(self, flat_grad: torch.Tensor, group=None, bucket_mb: float = 64.0, time_finish: bool = False):
         self.flat = flat_grad
+        # exposed communication: how long the compute stream sits in finish() waiting for collectives that the
+        # backward pass did not hide.  On the GPU a work.wait() only makes the stream wait (the host runs on), so the
+        # figure comes from two events around the waits; read it with exposed_ms() after a synchronize.
+        self.time_finish = bool(time_finish)
+        self._events = []
+        self.last_finish_ms = 0.0
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.buckets = plan_buckets(flat_grad.numel(), int(bucket_mb * (1 << 20) / 4))
@@ -62,11 +68,38 @@ class GradBucketReducer:
         if self.world == 1:
             return
         self.ready(0)
+        ev = None
+        t0 = 0.0
+        if self.time_finish:
+            if self.flat.is_cuda:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+            else:
+                import time
+                t0 = time.perf_counter()
         for w, lo, hi in self._works:
             w.wait()
-            if not self._avg:
+        if ev is not None:
+            ev[1].record()
+            self._events.append(ev)
+        elif self.time_finish:
+            import time
+            self.last_finish_ms = (time.perf_counter() - t0) * 1e3
+        if not self._avg:
+            for w, lo, hi in self._works:
                 self.flat[lo:hi].mul_(1.0 / self.world)
         self._works = []
+
+    def exposed_ms(self, reset: bool = True) -> float:
+        """sum over the finish() calls since the last reset of the time the compute stream waited for collectives
+        (synchronises the device)."""
+        if self._events:
+            torch.cuda.synchronize(self.flat.device)
+            tot = sum(a.elapsed_time(b) for a, b in self._events)
+            if reset:
+                self._events = []
+            return float(tot)
+        return float(self.last_finish_ms)
 
 
 def broadcast_params(flat: torch.Tensor, src: int = 0, group=None):

@@ -44,9 +44,10 @@ class Engine:
         self._ident: Dict[tuple, Stats] = {}
         self.precision = ops.PREC_F32  # arithmetic of the conv contractions (set_precision)
         self._flat16: Optional[torch.Tensor] = None  # bf16 image of the parameter arena (bf16 mode)
-        # bf16 mode: bf16 images of GroupNorm+SiLU'd conv inputs, kept from a recording forward for that layer's wgrad
-        self._a16: Dict[int, torch.Tensor] = {}
-        self._keep16 = False
+        # bf16 mode: the bf16 image of the GroupNorm+SiLU'd input the LAST _conv call made (None if it made none); a
+        # recording caller takes it right away (_take16) into its backward closure, so the image lives and dies with
+        # the tape that recorded it (two recorded forwards before one backward keep two images; an abandoned tape frees its own)
+        self._last16: Optional[torch.Tensor] = None
         # activation checkpointing of the decoder (BASELINE config 5): every resnet / attention / sampler of the decoder
         # keeps only its input; its forward is run again (recording) right before its own backward
         self.checkpoint_decoder = False
@@ -204,8 +205,7 @@ class Engine:
         if xf != XF_NONE and ops.act_image_ok(kind, x.shape, m.weight.shape[0], m.weight.shape[1]):
             # transform and round once (2 B/element written); forward and wgrad then read the image and transform nothing
             a16 = ops.gn_apply_bf16(x, st, xf)
-            if self._keep16:
-                self._a16[id(m)] = a16
+        self._last16 = a16
         # every 3x3 output of this model feeds a GroupNorm(32) next (or is summed first: then the statistics are dropped)
         want_stats = ops.GN_GROUPS if (kind in ("c3", "c3up") and (res is None or fuse_res)) else None
         y = ops.conv_fwd(x, m.weight, m.bias, kind, xf=xf, stats=st, res=res if fuse_res else None, track=tb, a16=a16,
@@ -220,9 +220,13 @@ class Engine:
             y = ops.add(y, res)
         return y
 
-    def _conv_bwd(self, m, x, dy, xf, st, need_dx=True):
+    def _take16(self, recording: bool) -> Optional[torch.Tensor]:
+        a16, self._last16 = self._last16, None
+        return a16 if recording else None
+
+    def _conv_bwd(self, m, x, dy, xf, st, need_dx=True, x16=None):
         kind = getattr(m, "kind", "c1")
-        ops.conv_wgrad(dy, x, kind, self._g(m.weight), self._g(m.bias), xf=xf, stats=st, x16=self._a16.pop(id(m), None))
+        ops.conv_wgrad(dy, x, kind, self._g(m.weight), self._g(m.bias), xf=xf, stats=st, x16=x16)
         if need_dx:
             return ops.conv_dgrad(dy, m.weight, kind, (x.shape[1], x.shape[2]))
         return None
@@ -266,18 +270,20 @@ class Engine:
         self._no_hooks(r.nonlinearity, "ResnetBlock2D.nonlinearity")
         self._no_hooks(r.dropout, "ResnetBlock2D.dropout")
         self._pre(r, lambda: x)
-        self._keep16 = tape is not None
+        rec = tape is not None
         st1 = self._gn(r.norm1, x)
         h = self._conv(r.conv1, x, XF_AFFINE_SILU, st1)
+        x16 = self._take16(rec)
         st2 = self._gn(r.norm2, h)
         sc = self._conv(r.conv_shortcut, x, XF_NONE, None) if r.conv_shortcut is not None else x
         out = self._conv(r.conv2, h, XF_AFFINE_SILU, st2, res=sc)
+        h16 = self._take16(rec)
         self._post(r, lambda: x, out)
         if tape is not None:
             def bwd(dout):
-                g2 = self._conv_bwd(r.conv2, h, dout, XF_AFFINE_SILU, st2)
+                g2 = self._conv_bwd(r.conv2, h, dout, XF_AFFINE_SILU, st2, x16=h16)
                 dh = self._gn_bwd(r.norm2, h, g2, st2, True, None)
-                g1 = self._conv_bwd(r.conv1, x, dh, XF_AFFINE_SILU, st1)
+                g1 = self._conv_bwd(r.conv1, x, dh, XF_AFFINE_SILU, st1, x16=x16)
                 dsc = self._conv_bwd(r.conv_shortcut, x, dout, XF_NONE, None) if r.conv_shortcut is not None else dout
                 dx = self._gn_bwd(r.norm1, x, g1, st1, True, dsc)
                 if notify is True:
@@ -353,9 +359,10 @@ class Engine:
         self._no_hooks(act, "conv_act")
         st = self._gn(norm, x)
         y = self._conv(conv, x, XF_AFFINE_SILU, st)
+        x16 = self._take16(tape is not None)
         if tape is not None:
             def bwd(d):
-                g = self._conv_bwd(conv, x, d, XF_AFFINE_SILU, st)
+                g = self._conv_bwd(conv, x, d, XF_AFFINE_SILU, st, x16=x16)
                 dx = self._gn_bwd(norm, x, g, st, True, None)
                 self._done(conv)
                 self._done(norm)

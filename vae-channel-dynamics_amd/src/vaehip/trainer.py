@@ -26,7 +26,7 @@ class HipTrainer:
     def __init__(self, wrapper, *, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=1.0,
                  kl_weight=1e-6, lr_warmup_steps=100, max_train_steps=1000, scheduler_steps_per_update: int = 1,
                  bucket_mb: float = 64.0, generator: Optional[torch.Generator] = None, mixed_precision: str = "no",
-                 gradient_accumulation_steps: int = 1, checkpoint_decoder: bool = False):
+                 gradient_accumulation_steps: int = 1, checkpoint_decoder: bool = False, time_comm: bool = False):
         self.wrapper = wrapper
         self.vae = wrapper.vae
         self.kl_weight = float(kl_weight)
@@ -41,16 +41,17 @@ class HipTrainer:
         self.micro_step = 0
         self._accum: Optional[torch.Tensor] = None
         self.bucket_mb = float(bucket_mb)
+        self.time_comm = bool(time_comm)
         self.optimizer = FusedAdamW(self.vae, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
                                     max_grad_norm=max_grad_norm)
         self.lr_scheduler = torch.optim.lr_scheduler.LambdaLR(self.optimizer, lr_lambda_factory(lr_warmup_steps, max_train_steps))
         # accelerate steps the scheduler num_processes times per optimizer step (accelerate/scheduler.py:72-82)
         self.scheduler_steps_per_update = int(scheduler_steps_per_update)
         self.world = dist.get_world_size() if dist.is_initialized() else 1
-        self.reducer = None
+        self.reducer: Optional[GradBucketReducer] = None   # made on first use (arena.grad exists after the first backward)
+        self._accum_reducer: Optional[GradBucketReducer] = None
         if self.world > 1:
             broadcast_params(self.vae.arena.flat, 0)
-            self.reducer = GradBucketReducer(self.vae.arena.grad, bucket_mb=bucket_mb)
         self.global_step = 0
         self.last = None
 
@@ -59,53 +60,112 @@ class HipTrainer:
         """True when the LAST train_step call ended with an optimizer update (accelerator.sync_gradients)."""
         return self.micro_step == 0
 
-    def _accumulating_step(self, pixel_values, eps):
-        """one micro-batch of an N-micro-batch update; returns (result, update_due)."""
-        eng = self.vae.engine
-        res = eng.forward_backward(pixel_values, eps, self.kl_weight, True, self.generator, grad_scale=1.0 / self.accum_steps)
-        grad = self.vae.arena.grad
-        self.micro_step += 1
-        if self.micro_step == 1:
-            if self._accum is None or self._accum.shape != grad.shape:
-                self._accum = torch.empty_like(grad)
-            self._accum.copy_(grad)
-            return res, False
-        last = self.micro_step == self.accum_steps
-        dst = grad if last else self._accum   # the sum ends up in arena.grad, where the optimizer reads it
-        ops.lib.call("vae_add", ops._p(self._accum), ops._p(grad), grad.numel(), ops._p(dst), ops._stream())
-        if last and self.world > 1:           # one exchange per update (no_sync on the other micro-batches)
-            allreduce_mean_(grad)
-        return res, last
+    def _make_reducer(self, flat: torch.Tensor) -> GradBucketReducer:
+        return GradBucketReducer(flat, bucket_mb=self.bucket_mb, time_finish=self.time_comm)
 
-    def train_step(self, pixel_values: torch.Tensor, eps: Optional[torch.Tensor] = None):
+    def _accumulating_step(self, pixel_values, eps, end_of_dataloader: bool):
+        """one micro-batch of an N-micro-batch update; returns (result, update_due).  The update is due on the N-th
+        micro-batch, or on the LAST batch of a dataloader pass whatever the count (accelerate's `accumulate` forces
+        sync_gradients there, accelerator.py:_do_sync; the 1/N loss scale stays, as in accelerate).
+        Exchange (world > 1): the mean over ranks is linear, so the sum of the earlier micro-batches (`_accum`) is
+        all-reduced in buckets from the START of the due micro-batch -- under its whole forward + backward -- and that
+        micro-batch's own gradient goes through the watermark-driven reducer under its backward; the two means are then
+        added.  Nothing is exchanged on the other micro-batches (DDP no_sync)."""
+        eng = self.vae.engine
+        grad = self.vae.arena.grad
+        due = (self.micro_step + 1 == self.accum_steps) or bool(end_of_dataloader)
+        first = self.micro_step == 0
+        exchange = due and self.world > 1
+        acc_red = None
+        if exchange:
+            if not first:
+                if self._accum_reducer is None or self._accum_reducer.flat.data_ptr() != self._accum.data_ptr():
+                    self._accum_reducer = self._make_reducer(self._accum)
+                acc_red = self._accum_reducer
+                acc_red.begin()
+                acc_red.ready(0)  # every bucket of the earlier micro-batches' sum is final: all in flight now
+            if self.reducer is None or self.reducer.flat.data_ptr() != grad.data_ptr():
+                self.reducer = self._make_reducer(grad)
+            self.reducer.begin()
+            eng.reducer = self.reducer
+        try:
+            res = eng.forward_backward(pixel_values, eps, self.kl_weight, True, self.generator, grad_scale=1.0 / self.accum_steps)
+        finally:
+            eng.reducer = None
+        grad = self.vae.arena.grad
+        if exchange:
+            self.reducer.finish()
+            if acc_red is not None:
+                acc_red.finish()
+        self.micro_step += 1
+        if first:
+            if not due:
+                if self._accum is None or self._accum.shape != grad.shape:
+                    self._accum = torch.empty_like(grad)
+                self._accum.copy_(grad)
+            return res, due            # a one-micro-batch update (flush right after an update): grad is already the sum
+        dst = grad if due else self._accum   # the sum ends up in arena.grad, where the optimizer reads it
+        self._add(self._accum, grad, dst)
+        return res, due
+
+    @staticmethod
+    def _add(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor):
+        ops.lib.call("vae_add", ops._p(a), ops._p(b), a.numel(), ops._p(out), ops._stream())
+
+    def train_step(self, pixel_values: torch.Tensor, eps: Optional[torch.Tensor] = None, end_of_dataloader: bool = False):
         """one micro-batch; returns the engine result dict, result['scalars'] = device tensor [mse, kl, total] of THIS
         rank.  With gradient_accumulation_steps = N the optimizer / scheduler / global_step advance on every N-th call
-        (`sync_gradients` tells which)."""
+        and on a call with end_of_dataloader=True (`sync_gradients` tells which)."""
         eng = self.vae.engine
         if self.accum_steps > 1:
-            res, due = self._accumulating_step(pixel_values, eps)
+            res, due = self._accumulating_step(pixel_values, eps, end_of_dataloader)
             self.last = res
             if not due:
                 return res
             self.micro_step = 0
         else:
-            if self.reducer is not None:
-                if self.reducer.flat.data_ptr() != self.vae.arena.grad.data_ptr():
-                    self.reducer = GradBucketReducer(self.vae.arena.grad, bucket_mb=self.bucket_mb)
+            if self.world > 1:
+                if self.reducer is None or self.reducer.flat.data_ptr() != self.vae.arena.grad.data_ptr():
+                    self.reducer = self._make_reducer(self.vae.arena.grad)
                 self.reducer.begin()
                 eng.reducer = self.reducer
             try:
                 res = eng.forward_backward(pixel_values, eps, self.kl_weight, True, self.generator)
             finally:
                 eng.reducer = None
-            if self.reducer is not None:
+            if self.world > 1:
                 self.reducer.finish()
+        self._update()
+        self.last = res
+        return res
+
+    @property
+    def pending_micro_batches(self) -> int:
+        """micro-batches accumulated since the last optimizer update"""
+        return self.micro_step
+
+    def flush(self):
+        """optimizer update from the micro-batches accumulated so far, without a new one (a dataloader pass that ends
+        on a batch every rank skipped).  No-op when nothing is pending."""
+        if self.micro_step == 0:
+            return
+        grad = self.vae.arena.grad
+        grad.copy_(self._accum)
+        if self.world > 1:
+            allreduce_mean_(grad)
+        self.micro_step = 0
+        self._update()
+
+    def _update(self):
         self.optimizer.step()
         for _ in range(self.scheduler_steps_per_update):
             self.lr_scheduler.step()
         self.global_step += 1
-        self.last = res
-        return res
+
+    def exposed_comm_ms(self) -> float:
+        """time the compute stream waited in reducer.finish() since the last call (0 when the exchange was hidden under
+        the backward pass or the world is 1); needs time_comm=True; synchronises the device"""
+        return sum(r.exposed_ms() for r in (self.reducer, self._accum_reducer) if r is not None)
 
     @torch.no_grad()
     def eval_step(self, pixel_values: torch.Tensor):
