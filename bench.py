@@ -40,10 +40,11 @@ CLASSIFY_CFG = {
 }
 
 
-def cpu_baseline(budget_s: float = 15.0):
+def cpu_baseline(batch: int = 2, steps: int = 2):
     """reference-equivalent CPU path (PyTorch oracle) on the host cores: full train steps (fwd+loss+bwd+clip+AdamW,
-    3 tracker hooks) on a bounded sample of the same workload.  One step at batch 1 warms the libraries up at the full
-    resolution and sizes the sample: the largest batch <= the config's 16 whose step fits `budget_s`, then 2 timed steps."""
+    3 tracker hooks) on a bounded sample of the same workload: `steps` timed steps at batch `batch` after one untimed
+    warm-up step at 64x64 (library initialisation).  Batch 2 is the largest whose two timed steps fit ~40 s on the GPU
+    box's host (a batch-1 step takes 11-12 s there on 128 threads); the config batch of 16 would take minutes."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import vae_oracle as vo
     cores = torch.get_num_threads()
@@ -55,24 +56,21 @@ def cpu_baseline(budget_s: float = 15.0):
             vo.mean_abs_per_channel(out)
         hooks.append(mod.register_forward_hook(hook))
     tr = vo.OracleTrainer(o, max_steps=100)
-    t0 = time.perf_counter()
-    tr.step(vo.synthetic_pixels(1, RES, 41), vo.synthetic_eps(1, RES, 41))  # warm-up at full resolution, untimed
-    t1 = time.perf_counter() - t0
-    b = int(max(1, min(BATCH_PER_GPU, budget_s // max(t1, 1e-3))))
-    x, e = vo.synthetic_pixels(b, RES, 42), vo.synthetic_eps(b, RES, 42)
+    tr.step(vo.synthetic_pixels(1, 64, 41), vo.synthetic_eps(1, 64, 41))  # warm-up, untimed
+    x, e = vo.synthetic_pixels(batch, RES, 42), vo.synthetic_eps(batch, RES, 42)
     times = []
-    for _ in range(2):
+    for _ in range(steps):
         t0 = time.perf_counter()
         tr.step(x, e)
         times.append(time.perf_counter() - t0)
     for h in hooks:
         h.remove()
     dt = sum(times)
-    return {"value": round(b * len(times) / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
-            "step_seconds": [round(t, 2) for t in times], "warmup_step_seconds_batch1": round(t1, 2),
-            "sample": f"{len(times)} timed full train steps at batch {b} (largest batch <= {BATCH_PER_GPU} whose step fits "
-                      f"{budget_s:.0f} s; config batch is {BATCH_PER_GPU}) after one untimed step, 256x256, fp32, torch CPU "
-                      f"({cores} threads); oracle = plain-PyTorch restatement of the reference diffusers path"}
+    return {"value": round(batch * len(times) / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "step_seconds": [round(t, 2) for t in times],
+            "sample": f"{len(times)} timed full train steps at batch {batch} (config batch is {BATCH_PER_GPU}: bounded sample) after "
+                      f"one untimed 64x64 warm-up step, 256x256, fp32, torch CPU ({cores} threads); oracle = plain-PyTorch "
+                      f"restatement of the reference diffusers path"}
 
 
 def _free_port() -> int:
@@ -173,7 +171,7 @@ def main():
     nudger = None
     if args.nudge_interval > 0 and not args.no_tracking:
         from intervention.nudger import InterventionHandler
-        nudger = InterventionHandler(w.vae, {"enabled": True, "strategy": "gentle_nudge_gn_scale", "nudge_factor": 1.10,
+        nudger = InterventionHandler(w.vae, {"enabled": True, "strategy": "gentle_nudge_groupnorm_scale", "nudge_factor": 1.10,
                                              "max_scale_value": 1.5, "intervention_interval": args.nudge_interval})
     track_interval = TRACKING_CFG["track_interval"] if not nudger else min(TRACKING_CFG["track_interval"], args.nudge_interval)
     if monitor is not None:

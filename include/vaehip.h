@@ -200,6 +200,20 @@ int vae_softmax_rows(float* S, int64_t rows, int32_t cols, void* stream);       
 /* dS = P*(dP - rowsum(dP*P)) in place on dP                                        */
 int vae_softmax_bwd_rows(const float* P, float* dP, int64_t rows, int32_t cols, void* stream);
 
+/* ---- blockwise (flash-style) attention, single head of width C = 512 (K3; no T x T score matrix) ----
+ * replaces: scaled_dot_product_attention forward / backward inside diffusers' Attention (call sites
+ * sdxl_vae_wrapper.py:60,71) for sequences where the materialised scores would not be reasonable (T = 16384 at 1024x1024).
+ * q, k, v (and dout): [B][T][C]; fp32 when prec == VAE_PREC_F32 (exact fp32 MFMA), bf16 images (vae_pack_bf16) when
+ * prec == VAE_PREC_BF16.  o, dq, dk, dv: fp32 [B][T][C]; lse [B][T] = row log-sum-exp of the scaled scores (saved by the
+ * forward, P is recomputed from it in the backward); dsum [B][T]: workspace (rowsum(dO*O), written here).           */
+int vae_attn_supported(int32_t T, int32_t C);  /* 1 when the kernels serve this shape (C == 512, T % 64 == 0) */
+int vae_attn_fwd(const void* q, const void* k, const void* v, int32_t B, int32_t T, int32_t C, float scale, int32_t prec,
+                 float* o, float* lse, void* stream);
+/* o32 / do32: the fp32 output of the forward and its gradient (for dsum); dout: do32 in the operand precision */
+int vae_attn_bwd(const void* q, const void* k, const void* v, const void* dout, const float* o32, const float* do32,
+                 const float* lse, int32_t B, int32_t T, int32_t C, float scale, int32_t prec,
+                 float* dq, float* dk, float* dv, float* dsum, void* stream);
+
 /* ---- posterior sample + KL + MSE (K4,K6; train.py:289-291) ---- */
 /* moments [B][hw][2*L] -> z [B][hw][L] = mu + exp(.5*clamp(lv,-30,20))*eps (eps may be null => mode())
  * kl_partial [B][nblk] ; nblk = ceil(hw*L/256)                                       */
@@ -224,6 +238,18 @@ int vae_add(const float* a, const float* b, int64_t n, float* out, void* stream)
 /* dst[i] = bf16(src[i]) (round to nearest even): the bf16 weight image the bf16 kernels read through vae_igemm_args.Wh;
  * run on the whole parameter arena once per step (replaces the per-step autocast weight casts of the reference) */
 int vae_pack_bf16(const float* src, int64_t n, void* dst, void* stream);
+
+/* ---- input transform (replaces the per-item CPU chain of src/data_utils.py:24-30) ----
+ * Resize(shorter side -> R, bilinear exactly as Pillow resamples it) -> CenterCrop(R) -> RGB -> ToTensor -> Normalize(.5,.5)
+ * for `n` uint8 images of one size, src [n][H][W][C] (C = 3 RGB, or 1 = grey replicated), out fp32 [n][3][R][R] in [-1,1].
+ * bounds_x [R][2] = {first source column, count}, kk_x [R][ksx]: Pillow's 22-bit fixed-point coefficients of the R output
+ * COLUMNS inside the centre crop; bounds_y / kk_y likewise for the R output rows (built by vaehip/preprocess.py from the
+ * sizes).  Only source rows [row0, row0 + nrows) feed the crop; tmp: workspace u8 [n][nrows][R][3] (the 8-bit
+ * intermediate between the two passes).  Integer arithmetic: bit-identical to the CPU path.                          */
+int vae_preprocess_u8(const uint8_t* src, int32_t n, int32_t H, int32_t W, int32_t C, int32_t R,
+                      const int32_t* bounds_x, const int32_t* kk_x, int32_t ksx,
+                      const int32_t* bounds_y, const int32_t* kk_y, int32_t ksy,
+                      int32_t row0, int32_t nrows, uint8_t* tmp, float* out, void* stream);
 
 /* ---- optimizer (K8,K9; train.py:184-187,301-302) ---- */
 /* sum of squares of g[0..n): stage 1 -> ws[nblk], stage 2 -> out[0]                   */

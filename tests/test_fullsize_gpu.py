@@ -71,3 +71,157 @@ def test_full_size_step_properties(model, mode, tol, gtol):
             assert float(((0.5 * (ta[n] + tb[n]) - t1[n]).abs() / t1[n].abs()).max()) < gtol, n
     finally:
         eng.set_precision("no")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[2], [3], [4] at their per-GPU shapes (the 8-rank exchange itself is covered by the DP tests and
+# the driver's scaling bench; here: one rank's step at the full per-GPU size, through the properties the domain offers)
+# ---------------------------------------------------------------------------------------------------------------------
+def test_config2_256_batch32_bf16(model):
+    """configs[2]: 256x256, batch 32 per GPU, bf16 compute, tracking on.  Determinism (bitwise) and the batch-mean
+    property (32 images = mean of 16 + 16: per-sample GroupNorm, mean-reduced losses) on different tile counts and
+    split-K plans."""
+    import vae_oracle as vo
+    w = model
+    eng = w.vae.engine
+    eng.set_precision("bf16")
+    try:
+        B, R = 32, 256
+        x, eps = vo.synthetic_pixels(B, R, 43).cuda(), vo.synthetic_eps(B, R, 43).cuda()
+        s1, g1, t1 = _step(w, x, eps)
+        s2, g2, t2 = _step(w, x, eps)
+        assert torch.equal(s1, s2) and torch.equal(g1, g2) and all(torch.equal(t1[n], t2[n]) for n in TRACKED)
+        assert torch.isfinite(s1).all() and torch.isfinite(g1).all() and float(g1.abs().max()) > 0
+        sa, ga, ta = _step(w, x[:16], eps[:16])
+        sb, gb, tb = _step(w, x[16:], eps[16:])
+        assert float((0.5 * (sa + sb) - s1).abs().max() / s1.abs().max()) < 5e-4
+        assert _rel(0.5 * (ga + gb), g1) < 2e-2
+        for n in TRACKED:
+            assert float(((0.5 * (ta[n] + tb[n]) - t1[n]).abs() / t1[n].abs()).max()) < 2e-2, n
+    finally:
+        eng.set_precision("no")
+
+
+def _nudged_run(cuda, steps, nudge_at, R=512, B=8, seed=5):
+    """`steps` optimizer steps of the reference's loop body (train.py:283-330) at configs[3]'s shape with the monitor,
+    classifier and InterventionHandler wired as train.py wires them; returns per-step losses, the nudged parameter after
+    every step, what the handler did, and the final arena."""
+    import vae_oracle as vo
+    from classification.classifier import RegionClassifier
+    from intervention.nudger import InterventionHandler
+    from models.sdxl_vae_wrapper import SDXLVAEWrapper
+    from tracking.monitor import ActivityMonitor
+    from vaehip.trainer import HipTrainer
+    lid = "vae.decoder.up_blocks.1.resnets.0.norm1.output"
+    w = SDXLVAEWrapper("synthetic:%d" % seed, device=cuda)
+    tr = HipTrainer(w, lr=1e-4, lr_warmup_steps=0, max_train_steps=100, kl_weight=1e-6, max_grad_norm=1.0, mixed_precision="bf16")
+    mon = ActivityMonitor(w, {"enabled": True, "track_interval": 1, "target_layers": [
+        {"name": lid[:-len(".output")], "capture_point": "output", "metrics": ["mean_abs_activation_per_channel"]}]})
+    gamma = w.vae.get_parameter("decoder.up_blocks.1.resnets.0.norm1.weight")
+    losses, gammas, events = [], [], []
+    thr = None
+    for s in range(1, steps + 1):
+        x, eps = vo.synthetic_pixels(B, R, 42, s).to(cuda), vo.synthetic_eps(B, R, 42, s).to(cuda)
+        res = tr.train_step(x, eps)
+        mon.step(s)
+        data = mon.get_data_for_step(s)
+        vals = data[lid]["mean_abs_activation_per_channel"]
+        if thr is None:  # a threshold that splits this layer's channels (random-init statistics cluster near 0.8)
+            thr = float(sorted(vals.tolist())[len(vals) // 4])
+        cls = RegionClassifier(w.vae, {"enabled": True, "threshold": thr, "layers_to_classify": [lid]}).classify(data, s)
+        if s in nudge_at:
+            before = gamma.detach().clone()
+            h = InterventionHandler(w.vae, {"enabled": True, "strategy": "gentle_nudge_groupnorm_scale", "nudge_factor": 1.10,
+                                            "max_scale_value": 1.5, "intervention_interval": s})
+            h.intervene(cls, s)
+            idx = cls[lid]["inactive_channel_indices"]
+            events.append((s, idx, h.num_nudges_applied, before, gamma.detach().clone()))
+        losses.append(res["scalars"].cpu().tolist())
+        gammas.append(gamma.detach().cpu().clone())
+    torch.cuda.synchronize()
+    return losses, gammas, events, w.vae.arena.flat.detach().clone()
+
+
+def test_config3_512_batch8_bf16_with_nudge_in_the_loop(cuda):
+    """configs[3]: 512x512, batch 8, bf16, InterventionHandler firing inside the step loop (train.py:315-330).
+    (1) the nudge is the reference's arithmetic on the LIVE parameter: gamma[idx] = fp32(min(fp64(gamma[idx]) * 1.10, 1.5));
+    (2) the next step reads it (its loss differs from the un-nudged twin, all earlier losses are bitwise equal);
+    (3) replicas stay identical: two independent runs of the nudged loop end in bitwise identical arenas."""
+    import numpy as np
+    la, ga, ea, fa = _nudged_run(cuda, steps=3, nudge_at={2})
+    lb, gb, eb, fb = _nudged_run(cuda, steps=3, nudge_at={2})
+    lc, gc, ec, fc = _nudged_run(cuda, steps=3, nudge_at=set())
+    assert torch.equal(fa, fb) and la == lb                      # (3)
+    (s, idx, n_applied, before, after), = ea
+    assert s == 2 and len(idx) > 0 and n_applied == len(idx)
+    want = before.cpu().numpy().copy()
+    for i in idx:                                                # (1) nudger.py:128-143 in fp64, one rounding to fp32
+        want[i] = np.float32(min(float(want[i]) * 1.10, 1.5))
+    assert np.array_equal(after.cpu().numpy(), want)
+    untouched = [i for i in range(want.shape[0]) if i not in set(idx)]
+    assert torch.equal(after[untouched], before[untouched])
+    assert la[0] == lc[0] and la[1] == lc[1]                     # (2) identical until the nudge ...
+    assert la[2] != lc[2]                                        # ... and the step after it sees the new gamma
+    assert abs(la[2][2] - lc[2][2]) / abs(lc[2][2]) < 0.2        # a nudge, not a blow-up
+    assert all(np.isfinite(v).all() for v in (np.array(la), fa.cpu().numpy()))
+
+
+def test_config4_1024_batch2_checkpointed_decoder(cuda):
+    """configs[4]: 1024x1024, batch 2, decoder activation-checkpointed, tracking + classification on (bf16 compute).
+    Re-running a decoder segment before its backward uses the same deterministic kernels: losses, every gradient and the
+    tracker vectors are BITWISE those of the un-checkpointed step, the peak HBM footprint is lower, and the trackers fire
+    once per layer (not again in the replay).  T = 16384 tokens in the mid-block attention: no B x T x T tensor."""
+    import vae_oracle as vo
+    from classification.classifier import RegionClassifier
+    from models.sdxl_vae_wrapper import SDXLVAEWrapper
+    w = SDXLVAEWrapper("synthetic:9", device=cuda)
+    eng = w.vae.engine
+    eng.set_precision("bf16")
+    B, R = 2, 1024
+    x, eps = vo.synthetic_pixels(B, R, 44).cuda(), vo.synthetic_eps(B, R, 44).cuda()
+
+    from vaehip import ops
+    n0 = dict(ops.ATTN_CALLS)
+
+    def run(ckpt):
+        eng.checkpoint_decoder = ckpt
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+        fired = {n: 0 for n in TRACKED}
+        got = {}
+
+        def sink(n):
+            def f(v):
+                fired[n] += 1
+                got[n] = v.clone()
+            return f
+        hs = [eng.add_tracker(w.vae.get_submodule(n), "output", sink(n)) for n in TRACKED]
+        res = eng.forward_backward(x, eps, 1e-6)
+        for h in hs:
+            h.remove()
+        torch.cuda.synchronize()
+        return res["scalars"].clone(), w.vae.arena.grad.clone(), got, fired, torch.cuda.max_memory_allocated()
+
+    try:
+        s0, g0, t0, f0, m0 = run(False)
+        s1, g1, t1, f1, m1 = run(True)
+    finally:
+        eng.checkpoint_decoder = False
+        eng.set_precision("no")
+    assert torch.equal(s0, s1) and torch.equal(g0, g1)
+    assert all(torch.equal(t0[n], t1[n]) for n in TRACKED)
+    assert all(v == 1 for v in f0.values()) and all(v == 1 for v in f1.values())
+    assert torch.isfinite(s0).all() and torch.isfinite(g0).all() and float(g0.abs().max()) > 0
+    assert m1 < 0.8 * m0, (m0, m1)
+    # T = 16384: both mid blocks ran on the blockwise kernels in both runs (the checkpointed decoder re-runs its forward), and
+    # no B x T x T score tensor was ever made (the materialised path was not taken)
+    assert ops.ATTN_CALLS["materialised_fwd"] == n0["materialised_fwd"]
+    assert ops.ATTN_CALLS["blockwise_fwd"] == n0["blockwise_fwd"] + 5 and ops.ATTN_CALLS["blockwise_bwd"] == n0["blockwise_bwd"] + 4
+    # classification on the tracked decoder layer runs on these statistics
+    lid = "vae.decoder.up_blocks.1.resnets.0.norm1.output"
+    vals = t1["decoder.up_blocks.1.resnets.0.norm1"].cpu().numpy()
+    thr = float(sorted(vals.tolist())[len(vals) // 2])
+    out = RegionClassifier(w.vae, {"enabled": True, "threshold": thr, "layers_to_classify": [lid]}).classify(
+        {lid: {"mean_abs_activation_per_channel": vals}}, 1)
+    assert 0 < len(out[lid]["inactive_channel_indices"]) < vals.shape[0]

@@ -7,6 +7,10 @@ The reference needs `torchvision` + a Hub download.  Here:
                                     Resize(shorter side, bilinear) -> CenterCrop -> RGB -> [0,1] -> (x-0.5)/0.5
                                     -- the same transform chain as data_utils.py:24-30 without torchvision
   anything else                     handed to `datasets.load_dataset` (works only with a populated HF cache)
+
+`data.gpu_preprocess: true` (a key the reference does not have) moves Resize / CenterCrop / ToTensor / Normalize to the
+GPU: workers only decode, batches of raw uint8 images go to the device and `vaehip.preprocess.GpuPreprocessor` produces
+the same tensors bit for bit (the per-item CPU resize is what limits an 8-GPU node at >= 200 images/s per GPU).
 """
 import logging
 import os
@@ -52,8 +56,17 @@ class SyntheticImageDataset(Dataset):
         return {"pixel_values": torch.rand((3, self.res, self.res), generator=g) * 2 - 1}
 
 
+def raw_item(img, tf) -> Dict[str, Any]:
+    """item for the GPU transform: the decoded bytes ("RGB" / "L" images, which the kernel resamples like Pillow); any
+    other mode (palette, alpha, CMYK ...) goes through the CPU chain, whose mode-specific resampling is not restated"""
+    if img.mode in ("RGB", "L"):
+        return {"pixel_u8": torch.from_numpy(np.asarray(img, dtype=np.uint8).copy())}
+    return {"pixel_values": tf(img)}
+
+
 class ImageFolderDataset(Dataset):
-    def __init__(self, root: str, resolution: int, max_samples: Optional[int] = None):
+    def __init__(self, root: str, resolution: int, max_samples: Optional[int] = None, raw: bool = False):
+        self.raw = bool(raw)
         files: List[str] = []
         for d, _, fs in sorted(os.walk(root)):
             files += [os.path.join(d, f) for f in sorted(fs) if f.lower().endswith(IMG_EXT)]
@@ -69,7 +82,7 @@ class ImageFolderDataset(Dataset):
         from PIL import Image
         try:
             with Image.open(self.files[i]) as im:
-                return {"pixel_values": self.tf(im)}
+                return raw_item(im, self.tf) if self.raw else {"pixel_values": self.tf(im)}
         except Exception as e:  # mirrors transform_images' per-item error handling (data_utils.py:121-152)
             logger.error(f"Failed to load {self.files[i]}: {e}")
             return {"pixel_values": None}
@@ -77,7 +90,7 @@ class ImageFolderDataset(Dataset):
 
 def load_and_preprocess_dataset(dataset_name: str, dataset_config_name: Optional[str] = None, image_column: str = "image",
                                 resolution: int = 256, max_samples: Optional[int] = None, split: str = "train",
-                                streaming: bool = False, cache_dir: Optional[str] = None):
+                                streaming: bool = False, cache_dir: Optional[str] = None, gpu_preprocess: bool = False):
     if dataset_name is None:
         raise ValueError("data.dataset_name is required")
     if dataset_name.startswith("synthetic"):
@@ -90,7 +103,7 @@ def load_and_preprocess_dataset(dataset_name: str, dataset_config_name: Optional
     if os.path.isdir(dataset_name):
         root = os.path.join(dataset_name, split) if os.path.isdir(os.path.join(dataset_name, split)) else dataset_name
         logger.info(f"Local image folder dataset: {root}")
-        return ImageFolderDataset(root, resolution, max_samples)
+        return ImageFolderDataset(root, resolution, max_samples, raw=gpu_preprocess)
     from datasets import load_dataset  # needs a populated local HF cache: there is no network in this build
     logger.info(f"Loading dataset '{dataset_name}' (config: {dataset_config_name}, split: {split}) via datasets")
     ds = load_dataset(dataset_name, dataset_config_name, split=split, streaming=streaming, cache_dir=cache_dir)
@@ -109,7 +122,17 @@ def load_and_preprocess_dataset(dataset_name: str, dataset_config_name: Optional
                 logger.error(f"transform failed: {e}")
                 out.append(None)
         return {"pixel_values": out}
-    return ds.with_transform(transform_images)
+
+    def raw_images(examples):
+        items = []
+        for im in examples[image_column]:
+            try:
+                items.append(raw_item(im, tf))
+            except Exception as e:
+                logger.error(f"decode failed: {e}")
+                items.append({})
+        return {"pixel_u8": [it.get("pixel_u8") for it in items], "pixel_values": [it.get("pixel_values") for it in items]}
+    return ds.with_transform(raw_images if gpu_preprocess else transform_images)
 
 
 def safe_collate(batch):
@@ -126,9 +149,57 @@ def safe_collate(batch):
         return None
 
 
+def raw_collate(batch):
+    """collate for the GPU transform: images differ in size, so the batch is a list (uint8 [H][W](x3) tensors, or fp32
+    [3][R][R] tensors of items the CPU chain handled); failed items are dropped like safe_collate does"""
+    items = []
+    for b in batch:
+        t = b.get("pixel_u8")
+        if t is None:
+            t = b.get("pixel_values")
+        if t is not None and len(t) > 0:
+            items.append(t)
+    if len(items) < len(batch):
+        logger.warning(f"Collate function filtered {len(batch) - len(items)} items due to missing/empty images.")
+    return {"items": items} if items else None
+
+
+class GpuTransformLoader:
+    """wraps a DataLoader of raw batches: yields {"pixel_values": fp32 CUDA tensor [N][3][R][R]} like the CPU pipeline"""
+
+    def __init__(self, loader: DataLoader, preprocessor):
+        self.loader, self.pre = loader, preprocessor
+        self.sampler, self.dataset, self.batch_size = loader.sampler, loader.dataset, loader.batch_size
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        for batch in self.loader:
+            if not batch:
+                yield None
+                continue
+            items = batch["items"]
+            u8 = [i for i, t in enumerate(items) if t.dtype == torch.uint8]
+            if len(u8) == len(items):
+                yield {"pixel_values": self.pre(items)}
+                continue
+            out = torch.empty((len(items), 3, self.pre.res, self.pre.res), device=self.pre.device, dtype=torch.float32)
+            if u8:
+                out[torch.tensor(u8, device=out.device)] = self.pre([items[i] for i in u8])
+            for i, t in enumerate(items):
+                if t.dtype != torch.uint8:
+                    out[i] = t.to(out.device, dtype=torch.float32)
+            yield {"pixel_values": out}
+
+
 def create_dataloader(dataset, batch_size: int, num_workers: int = 0, shuffle: bool = True, pin_memory: bool = True,
-                      collate_fn=None, rank: int = 0, world_size: int = 1, seed: int = 42) -> DataLoader:
-    """per-rank shard when world_size > 1 (what accelerate.prepare does to the reference's dataloader, train.py:205-210)."""
+                      collate_fn=None, rank: int = 0, world_size: int = 1, seed: int = 42, gpu_preprocess=None):
+    """per-rank shard when world_size > 1 (what accelerate.prepare does to the reference's dataloader, train.py:205-210).
+    gpu_preprocess: a vaehip.preprocess.GpuPreprocessor for datasets loaded with gpu_preprocess=True."""
+    if gpu_preprocess is not None and not isinstance(dataset, SyntheticImageDataset):
+        inner = create_dataloader(dataset, batch_size, num_workers, shuffle, pin_memory, raw_collate, rank, world_size, seed)
+        return GpuTransformLoader(inner, gpu_preprocess)
     is_iterable = isinstance(dataset, torch.utils.data.IterableDataset)
     sampler = None
     if world_size > 1 and not is_iterable:

@@ -54,7 +54,11 @@ def psnr_sums(pred: torch.Tensor, target: torch.Tensor):
 
 
 def ssim_per_image(pred: torch.Tensor, target: torch.Tensor, sigma: float = 1.5, ksize: int = 11) -> torch.Tensor:
-    """SSIM with a gaussian window (data_range 1.0, k1=0.01, k2=0.03), reflect-padded like torchmetrics."""
+    """SSIM with a gaussian window (data_range 1.0, k1=0.01, k2=0.03), reflect-padded and border-cropped like torchmetrics.
+    The window statistics are taken in float64: var = E[x^2] - mu^2 cancels catastrophically in fp32 on flat regions
+    (errors of 1e-4 in the index against the 9e-4 stabiliser c2); torchmetrics itself works in the input dtype."""
+    out_dtype = pred.dtype
+    pred, target = pred.double(), target.double()
     c = pred.shape[1]
     ax = torch.arange(ksize, dtype=pred.dtype, device=pred.device) - (ksize - 1) / 2
     g = torch.exp(-(ax / sigma) ** 2 / 2)
@@ -69,7 +73,7 @@ def ssim_per_image(pred: torch.Tensor, target: torch.Tensor, sigma: float = 1.5,
     s_pp, s_tt, s_pt = e_pp - mu_p ** 2, e_tt - mu_t ** 2, e_pt - mu_p * mu_t
     c1, c2 = 0.01 ** 2, 0.03 ** 2
     ssim = ((2 * mu_p * mu_t + c1) * (2 * s_pt + c2)) / ((mu_p ** 2 + mu_t ** 2 + c1) * (s_pp + s_tt + c2))
-    return ssim[..., pad:-pad, pad:-pad].reshape(pred.shape[0], -1).mean(-1)
+    return ssim[..., pad:-pad, pad:-pad].reshape(pred.shape[0], -1).mean(-1).to(out_dtype)
 
 
 def save_png(t: torch.Tensor, path: str):

@@ -237,22 +237,31 @@ def main():
                                  torch_dtype=None, device=device)
     data_cfg = config.get("data", {})
     bs = data_cfg.get("batch_size", 4)
+    # data.gpu_preprocess (not a key of the reference): workers only decode; Resize / CenterCrop / Normalize run on the GPU
+    gpu_pre = None
+    if data_cfg.get("gpu_preprocess", False):
+        from vaehip.preprocess import GpuPreprocessor
+        gpu_pre = GpuPreprocessor(data_cfg.get("resolution", 256), device)
     train_dataset = load_and_preprocess_dataset(
+        gpu_preprocess=gpu_pre is not None,
         dataset_name=data_cfg.get("dataset_name"), dataset_config_name=data_cfg.get("dataset_config_name", None),
         image_column=data_cfg.get("image_column", "image"), resolution=data_cfg.get("resolution", 256),
         max_samples=data_cfg.get("max_samples", None), split=data_cfg.get("train_split_name", "train"))
     train_dataloader = create_dataloader(train_dataset, batch_size=bs, num_workers=data_cfg.get("num_workers", 0),
-                                         shuffle=True, rank=rank, world_size=world, seed=int(config.get("seed") or 0))
+                                         shuffle=True, rank=rank, world_size=world, seed=int(config.get("seed") or 0),
+                                         gpu_preprocess=gpu_pre)
     val_dataloader = None
     if data_cfg.get("do_validation", False):
         try:
             vds = load_and_preprocess_dataset(
+                gpu_preprocess=gpu_pre is not None,
                 dataset_name=data_cfg.get("validation_dataset_name", data_cfg.get("dataset_name")),
                 dataset_config_name=data_cfg.get("validation_dataset_config_name", data_cfg.get("dataset_config_name", None)),
                 image_column=data_cfg.get("image_column", "image"), resolution=data_cfg.get("resolution", 256),
                 max_samples=data_cfg.get("validation_max_samples", None), split=data_cfg.get("validation_split_name", "validation"))
             val_dataloader = create_dataloader(vds, batch_size=data_cfg.get("validation_batch_size", bs),
-                                               num_workers=data_cfg.get("num_workers", 0), shuffle=False, rank=rank, world_size=world)
+                                               num_workers=data_cfg.get("num_workers", 0), shuffle=False, rank=rank, world_size=world,
+                                               gpu_preprocess=gpu_pre)
         except Exception as e:
             logger.error(f"Failed to load validation data: {e}. Disabling validation.")
             data_cfg["do_validation"] = False

@@ -304,19 +304,34 @@ class Engine:
         k = self._conv(a.to_k, x, XF_AFFINE, st)
         v = self._conv(a.to_v, x, XF_AFFINE, st)
         qf, kf, vf = q.view(B, T, Cc), k.view(B, T, Cc), v.view(B, T, Cc)
-        P = ops.softmax_rows_(ops.gemm_nt(qf, kf, scale))
-        o = ops.gemm_nn(P, vf).view(B, H, W, Cc)
         self._no_hooks(a.to_out[1], "Attention.to_out.1 (dropout)")
+        # long sequences (R >= 512): blockwise kernels, online softmax, no T x T tensor; P is recomputed in the backward
+        # from the saved row log-sum-exp.  Short ones keep the materialised scores (4 MB per image at T = 1024).
+        blockwise = ops.attn_blockwise_ok(T, Cc)
+        if blockwise:
+            of, saved = ops.attn_fwd(qf, kf, vf, scale)
+            P = qf = kf = vf = None  # the saved operands (fp32 tensors or their bf16 images) are what the backward reads
+        else:
+            P = ops.softmax_rows_(ops.gemm_nt(qf, kf, scale))
+            of = ops.gemm_nn(P, vf)
+            ops.ATTN_CALLS["materialised_fwd"] += 1
+            saved = None
+        if tape is None:
+            P = saved = None
+        o = of.view(B, H, W, Cc)
         out = self._conv(a.to_out[0], o, XF_NONE, None, res=x)
         self._post(a, lambda: x, out)
         if tape is not None:
             def bwd(dout):
                 do = self._conv_bwd(a.to_out[0], o, dout, XF_NONE, None).view(B, T, Cc)
-                dP = ops.gemm_nt(do, vf)
-                dv = ops.gemm_tn(P, do)
-                dS = ops.softmax_bwd_rows_(P, dP)
-                dq = ops.gemm_nn(dS, kf, scale)
-                dk = ops.gemm_tn(dS, qf, scale)
+                if blockwise:
+                    dq, dk, dv = ops.attn_bwd(saved, of, do, scale)
+                else:
+                    dP = ops.gemm_nt(do, vf)
+                    dv = ops.gemm_tn(P, do)
+                    dS = ops.softmax_bwd_rows_(P, dP)
+                    dq = ops.gemm_nn(dS, kf, scale)
+                    dk = ops.gemm_tn(dS, qf, scale)
                 g = self._conv_bwd(a.to_q, x, dq.view(B, H, W, Cc), XF_AFFINE, st)
                 g = ops.add(g, self._conv_bwd(a.to_k, x, dk.view(B, H, W, Cc), XF_AFFINE, st))
                 g = ops.add(g, self._conv_bwd(a.to_v, x, dv.view(B, H, W, Cc), XF_AFFINE, st))

@@ -41,7 +41,7 @@ class WgradArgs(C.Structure):
 
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
-EXPECTED_ABI = 5  # vae_abi_version() of the library these structures and signatures describe
+EXPECTED_ABI = 6  # vae_abi_version() of the library these structures and signatures describe
 
 # name -> argtypes (every function returns int); must list EVERY symbol of include/vaehip.h
 SIGNATURES = {
@@ -67,6 +67,9 @@ SIGNATURES = {
     "vae_gn_bwd_partial": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp],
     "vae_gn_bwd_final": [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp],
     "vae_gn_bwd_apply": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp],
+    "vae_attn_supported": [i32, i32],
+    "vae_attn_fwd": [vp, vp, vp, i32, i32, i32, f32, i32, vp, vp, vp],
+    "vae_attn_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp],
     "vae_softmax_rows": [vp, i64, i32, vp],
     "vae_softmax_bwd_rows": [vp, vp, i64, i32, vp],
     "vae_sample_kl": [vp, vp, i32, i32, i32, vp, vp, vp],
@@ -79,6 +82,7 @@ SIGNATURES = {
     "vae_sumpool2x2": [vp, i32, i32, i32, i32, vp, vp],
     "vae_add": [vp, vp, i64, vp, vp],
     "vae_pack_bf16": [vp, i64, vp, vp],
+    "vae_preprocess_u8": [vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, i32, i32, vp, vp, vp],
     "vae_sqnorm": [vp, i64, vp, i32, vp, vp],
     "vae_adamw": [vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, f32, i32, vp],
     "vae_dead_scan": [vp, vp, i32, f32, vp, vp, vp],

@@ -604,6 +604,52 @@ def gemm_tn(A: torch.Tensor, Bm: torch.Tensor, alpha: float = 1.0) -> torch.Tens
     return out
 
 
+# ------------------------------------------------------------------ blockwise attention (no T x T tensor)
+# sequences of at least this many tokens run the blockwise kernels (R >= 512: T >= 4096); shorter ones keep the
+# materialised scores, which are small there (T = 1024: 4 MB per image).  Tests lower it to compare the two paths.
+ATTN_BLOCKWISE_MIN_T = 4096
+ATTN_CALLS = {"blockwise_fwd": 0, "blockwise_bwd": 0, "materialised_fwd": 0}
+
+
+def attn_blockwise_ok(T: int, Cc: int) -> bool:
+    return T >= ATTN_BLOCKWISE_MIN_T and bool(lib.query("vae_attn_supported", int(T), int(Cc)))
+
+
+def _attn_operand(t: torch.Tensor) -> torch.Tensor:
+    """operand of the attention kernels in the arithmetic's precision: the fp32 tensor itself, or its bf16 image"""
+    if PRECISION != PREC_BF16:
+        return t
+    return pack_bf16(t, torch.empty(t.shape, device=t.device, dtype=torch.bfloat16))
+
+
+def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float):
+    """q, k, v [B,T,C] fp32 -> (o [B,T,C] fp32, saved = operands + row log-sum-exp for attn_bwd)"""
+    B, T, Cc = q.shape
+    for t in (q, k, v):
+        _chk_c(t, "attn_fwd")
+    qe, ke, ve = _attn_operand(q), _attn_operand(k), _attn_operand(v)
+    o = torch.empty_like(q)
+    lse = torch.empty((B, T), device=q.device, dtype=torch.float32)
+    lib.call("vae_attn_fwd", _p(qe), _p(ke), _p(ve), B, T, Cc, float(scale), PRECISION, _p(o), _p(lse), _stream())
+    ATTN_CALLS["blockwise_fwd"] += 1
+    return o, (qe, ke, ve, lse, PRECISION)
+
+
+def attn_bwd(saved, o: torch.Tensor, do: torch.Tensor, scale: float):
+    """-> dq, dk, dv [B,T,C] fp32; P is recomputed blockwise from the saved log-sum-exp"""
+    qe, ke, ve, lse, prec = saved
+    B, T, Cc = o.shape
+    _chk_c(do, "attn_bwd.do")
+    with precision(prec):
+        doe = _attn_operand(do)
+    dq, dk, dv = torch.empty_like(o), torch.empty_like(o), torch.empty_like(o)
+    dsum = torch.empty((B, T), device=o.device, dtype=torch.float32)
+    lib.call("vae_attn_bwd", _p(qe), _p(ke), _p(ve), _p(doe), _p(o), _p(do), _p(lse), B, T, Cc, float(scale), prec,
+             _p(dq), _p(dk), _p(dv), _p(dsum), _stream())
+    ATTN_CALLS["blockwise_bwd"] += 1
+    return dq, dk, dv
+
+
 def softmax_rows_(S: torch.Tensor):
     cols = S.shape[-1]
     lib.call("vae_softmax_rows", _p(S), S.numel() // cols, cols, _stream())
