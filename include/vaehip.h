@@ -99,13 +99,17 @@ typedef struct vae_igemm_args {
   int32_t a_step, a_oy, a_ox;
   int32_t c_step, c_oy, c_ox;
   float* gstat;          /* optional (vae_conv_gstat_chunks(a) > 0): GroupNorm statistics of the OUTPUT from the epilogue:  */
-  int32_t gstat_groups;  /* ws[b][chunk][gstat_groups][2] = (sum, sum of squares) per output tile -- the layout
+  int32_t gstat_groups;  /* ws[b][chunk][gstat_groups][2] = (mean, M2) per output tile -- the layout
                           * vae_gn_stats_partial writes, so vae_gn_stats_final finishes it; saves re-reading the output */
+  int32_t out_bf16;      /* != 0 (vae_conv_out_bf16_ok(a)): C is a bf16 tensor (2 B per element, same [m][ldc] layout): the dgrad
+                          * outputs of bf16 mode, read back by vae_gn_bwd_* (g_bf16); no bias / res / track / gstat with it   */
 } vae_igemm_args;
 int vae_igemm_rows(const vae_igemm_args* a, void* stream);
 /* number of chunks per image the launch for `a` (with a->gstat_groups set) would write into a->gstat, or 0 when the
  * kernel serving it has no statistics epilogue (the caller then runs vae_gn_stats_partial on the output)           */
 int vae_conv_gstat_chunks(const vae_igemm_args* a);
+/* 1 when the kernel that would serve `a` can write a bf16 output (a->out_bf16): the bf16 halo-tile kernels, dgrad      */
+int vae_conv_out_bf16_ok(const vae_igemm_args* a);
 /* 1 when the kernel that would serve `a` honours tapmask / a_step.. / c_step.. (the halo-tile kernels), else 0     */
 int vae_conv_phase_ok(const vae_igemm_args* a);
 /* W [Co][3][3][Ci] (OHWI) -> Weff [4 phases (a*2+b)][Co][3][3][Ci]: the 3x3 kernel each output parity (a,b) of
@@ -135,6 +139,8 @@ typedef struct vae_wgrad_args {
   float alpha;
   int32_t prec;          /* VAE_PREC_* */
   const void* X16;       /* optional: as vae_igemm_args.A16, for X (xf must be NONE) */
+  const void* dY16;      /* optional (vae_bf16_grad_image_ok): bf16 image of dY, same [pix][ldy] layout; the kernel then reads it
+                          * instead of dY (which may be NULL): half the bytes, and no rounding pass in the kernel            */
   /* phase convolutions of an upsampler (vae_wgrad_phase_ok(a) != 0; zero-initialised = plain): pixel (y,x) of dY lives at
    * (y*y_step + y_oy, x*y_step + y_ox) of a tensor y_step times larger in H and W; only the taps in tapmask are computed
    * (the others are written as zeros).  vae_upconv_fold_wgrad turns the four phase results into the 3x3 gradient.     */
@@ -155,11 +161,16 @@ int vae_igemm_kernel_name(const vae_igemm_args* a, char* buf, int32_t n);
 int vae_wgrad_kernel_name(const vae_wgrad_args* a, char* buf, int32_t n);
 /* out[i] = sum_s partial[s][i], fixed order (deterministic)                     */
 int vae_reduce_splits(const float* partial, int32_t nsplit, int64_t n, float* out, void* stream);
+/* the same for two slabs with one nsplit in ONE launch: the weight-gradient partials and the (small) bias-gradient partials */
+int vae_reduce_splits2(const float* partial, int32_t nsplit, int64_t n, float* out, const float* partial2, int32_t n2, float* out2,
+                       void* stream);
 /* ---- GroupNorm (32 groups, eps 1e-6) replaces group_norm fwd/bwd (K2,K7) ---- */
-/* stage 1: per (b, chunk, group) partial sum / sumsq.  ws: [B][nchunk][G][2]     */
+/* stage 1: per (b, chunk, group) CENTRED moments ws [B][nchunk][G][2] = (mean, M2 = sum of squared deviations) of chunk
+ * `chunk` = pixels [chunk*per, min(HW, (chunk+1)*per)), per = ceil(HW/nchunk): shifted sums, no E[x^2]-mean^2 cancellation
+ * (torch's CPU group_norm, which the reference runs on, is a Welford pass; activations with |mean| >> std need it)     */
 int vae_gn_stats_partial(const float* x, int32_t B, int32_t HW, int32_t C, int32_t G,
                          int32_t nchunk, float* ws, void* stream);
-/* stage 2: mean/rstd [B][G] and the fused affine scale/shift [B][C]:
+/* stage 2: Chan's merge of the chunk moments in fp64 -> mean/rstd [B][G] and the fused affine scale/shift [B][C]:
  *   scale = rstd*gamma, shift = beta - mean*rstd*gamma                            */
 int vae_gn_stats_final(const float* ws, int32_t B, int32_t HW, int32_t C, int32_t G, int32_t nchunk,
                        const float* gamma, const float* beta, float eps,
@@ -174,26 +185,32 @@ int vae_gn_apply_bf16(const float* x, const float* scale, const float* shift, in
 /* 1 when BOTH the forward (vae_igemm_rows) and the weight gradient (vae_wgrad) of the 3x3 stride-1 layer with this
  * forward geometry, Cout and Cin accept a bf16 activation image in bf16 mode (the halo-tile kernels serve them)   */
 int vae_bf16_act_image_ok(const vae_conv_geom* fwd_geom, int32_t Cout, int32_t Cin);
+/* 1 when BOTH the dgrad (vae_igemm_rows, mode DGRAD, A16 = the bf16 gradient) and the weight gradient (vae_wgrad, dY16) of
+ * the 3x3 stride-1 layer with this forward geometry accept the output gradient as a bf16 image in bf16 mode            */
+int vae_bf16_grad_image_ok(const vae_conv_geom* fwd_geom, int32_t Cout, int32_t Cin);
 /* tracker (monitor.py:66): partial sums of |x*scale+shift| per (b,chunk,c);
  * ws [B][nchunk][C]; then vae_track_final                                         */
 int vae_gn_track_partial(const float* x, const float* scale, const float* shift, int32_t B, int32_t HW,
                          int32_t C, int32_t nchunk, float* ws, void* stream);
 /* out[c] = (sum over rows of ws[r][c]) * inv_count ; fixed order                   */
 int vae_track_final(const float* ws, int32_t rows, int32_t C, float inv_count, float* out, void* stream);
-/* GroupNorm(+SiLU) backward.  g = dL/d(XF(gn(x))).
+/* GroupNorm(+SiLU) backward.  g = dL/d(XF(gn(x))): fp32, or bf16 when g_bf16 != 0 (bf16 mode stores the dgrad outputs of
+ * the halo-tile kernels as bf16, vae_igemm_args.out_bf16).
  * stage 1: ws [B][nchunk][C][2] partial sums of du and du*xhat                     */
-int vae_gn_bwd_partial(const float* x, const float* g, const float* mean, const float* rstd,
+int vae_gn_bwd_partial(const float* x, const void* g, const float* mean, const float* rstd,
                        const float* gamma, const float* beta, int32_t B, int32_t HW, int32_t C, int32_t G,
-                       int32_t nchunk, int32_t silu, float* ws, void* stream);
+                       int32_t nchunk, int32_t silu, int32_t g_bf16, float* ws, void* stream);
 /* stage 2: dgamma/dbeta [C] (written, not accumulated) and coefficients
- * coef [B][G][2] = {rstd*s2/N, rstd*s1/N}; ws[b][0][c][:] is overwritten with the per-(b,c) totals                                        */
-int vae_gn_bwd_final(float* ws, const float* rstd, const float* gamma, int32_t B, int32_t HW,
+ * coef [B][G][2] = {rstd*s2/N, rstd*s1/N}; one launch (ws is only read)                                                  */
+int vae_gn_bwd_final(const float* ws, const float* rstd, const float* gamma, int32_t B, int32_t HW,
                      int32_t C, int32_t G, int32_t nchunk, float* dgamma, float* dbeta, float* coef,
                      void* stream);
-/* stage 3: dx = du*rstd*gamma - xhat*coef0 - coef1 (+ add)                          */
-int vae_gn_bwd_apply(const float* x, const float* g, const float* mean, const float* rstd,
+/* stage 3: dx = du*rstd*gamma - xhat*coef0 - coef1 (+ add), written as fp32 (dx) and / or as bf16 (dx16); at least one.
+ * A gradient that only feeds convolutions (dL/dh of a resnet) needs the bf16 copy alone -- the bf16 kernels would round it
+ * at the same point; one that also carries the residual stream gets both.                                              */
+int vae_gn_bwd_apply(const float* x, const void* g, const float* mean, const float* rstd,
                      const float* gamma, const float* beta, const float* coef, const float* add,
-                     int32_t B, int32_t HW, int32_t C, int32_t G, int32_t silu, float* dx, void* stream);
+                     int32_t B, int32_t HW, int32_t C, int32_t G, int32_t silu, int32_t g_bf16, float* dx, void* dx16, void* stream);
 
 /* ---- attention softmax (K3) ---- */
 int vae_softmax_rows(float* S, int64_t rows, int32_t cols, void* stream);           /* in place */
@@ -259,13 +276,19 @@ int vae_sqnorm(const float* g, int64_t n, float* ws, int32_t nblk, float* out, v
 int vae_adamw(float* p, const float* g, float* m, float* v, int64_t n, const float* sqnorm,
               float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
               int32_t step, void* stream);
-/* dead-weight scan (deadneuron.py:78-115): counts per segment of |w|<thr, and sum|w|;
- * seg_off [nseg][2] = {begin,end} element offsets into w (segments need not be adjacent);
- * out_counts [nseg] (u64), out_abssum [nseg] (double); one workgroup per segment, fixed order  */
-int vae_dead_scan(const float* w, const int64_t* seg_off, int32_t nseg, float thr,
-                  unsigned long long* out_counts, double* out_abssum, void* stream);
-int vae_dead_scan_adaptive(const float* w, const int64_t* seg_off, int32_t nseg, float thr, int32_t use_fixed,
-                           const float* adaptive_thr, unsigned long long* out_counts, void* stream);
+/* dead-weight scan (deadneuron.py:78-115): per segment, the count of |w| < thr and the sum of |w|.
+ * seg_off [nseg][2] = {begin,end} element offsets into w (segments need not be adjacent).  The segments are scanned in
+ * chunks of vae_dead_scan_chunk() elements, one workgroup per chunk: seg_chunk0 [nseg+1] = prefix sum of the segments'
+ * chunk counts (ceil(len / chunk)), nchunk = seg_chunk0[nseg]; part_counts / part_abssum [nchunk]: workspace.  A second
+ * kernel adds each segment's partials in chunk order: out_counts [nseg] (u64), out_abssum [nseg] (double), reproducible. */
+int vae_dead_scan_chunk(void);
+int vae_dead_scan(const float* w, const int64_t* seg_off, const int32_t* seg_chunk0, int32_t nseg, int32_t nchunk, float thr,
+                  unsigned long long* part_counts, double* part_abssum, unsigned long long* out_counts, double* out_abssum,
+                  void* stream);
+/* counts of |w| < adaptive_thr[seg] (and < thr when use_fixed): the "percent_of_mean" / "both" modes */
+int vae_dead_scan_adaptive(const float* w, const int64_t* seg_off, const int32_t* seg_chunk0, int32_t nseg, int32_t nchunk, float thr,
+                           int32_t use_fixed, const float* adaptive_thr, unsigned long long* part_counts,
+                           unsigned long long* out_counts, void* stream);
 
 #ifdef __cplusplus
 }

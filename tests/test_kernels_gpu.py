@@ -2,6 +2,7 @@
 CPU reference of the same op, on seeded inputs.  Tolerances: fp32 MFMA is an exact-product
 fp32 fmaf chain, so differences are summation-order only (1e-5 relative to the operand scale)."""
 import math
+import os
 
 import pytest
 import torch
@@ -497,8 +498,8 @@ def test_bf16_activation_image(cuda, bf16_mode, packed_weights, B, C, H, W, Co):
     finally:
         ops.PROFILER = None
     names = [r[0] for r in prof.records]
-    assert names[0].startswith("conv3_tile_bf16_kernel") and names[0].endswith(",true>"), names
-    assert names[1].startswith("wgrad3_tile_bf16_kernel") and names[1].endswith(",true>"), names
+    assert names[0] == "conv3_wide_bf16_kernel<false>" or (names[0].startswith("conv3_tile_bf16_kernel") and names[0].endswith(",true>")), names
+    assert names[1].startswith("wgrad3_tile_bf16_kernel") and ",true," in names[1], names  # <UP, XF, X16 = true, Y16>
     assert _rel(_nchw(y), F.conv2d(img, _r16(w), None, 1, 1)) < 2e-5
     wr = w.clone().requires_grad_(True)
     F.conv2d(img, wr, None, 1, 1).backward(_r16(dy))
@@ -610,3 +611,164 @@ def test_bf16_upconv_phase_decomposition(cuda, bf16_mode, packed_weights):
     assert _rel(_nchw(dx), gx) < 2e-5
     # and close to the fp32 upsample + conv at bf16 accuracy
     assert _rel(_nchw(y), F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, None, 1, 1)) < 2e-2
+
+
+# ---------------------------------------------------------------------------------------------------------
+# bf16 gradient images (bf16 mode): dgrad outputs stored as bf16 (out_bf16), GroupNorm backward reading a bf16 g and
+# writing fp32 and / or bf16, dgrad / wgrad reading the output gradient as a bf16 image (A16 / dY16)
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 8, 32, 128, 128), (1, 4, 64, 256, 512), (5, 128, 128, 128, 128), (2, 12, 32, 512, 256)])
+def test_bf16_gradient_images_conv(cuda, bf16_mode, packed_weights, B, H, W, Ci, Co):
+    from vaehip import ops
+    gen = torch.Generator().manual_seed(11 + Ci + Co)
+    x = torch.randn(B, Ci, H, W, generator=gen)
+    w = torch.randn(Co, Ci, 3, 3, generator=gen) / math.sqrt(Ci * 9)
+    dy = torch.randn(B, Co, H, W, generator=gen)
+    wd = packed_weights(_to_dev_ohwi(w))
+    assert ops.grad_image_ok("c3", (B, H, W, Ci), Co, Ci)
+    dyd = _nhwc(dy)
+    dy16 = dyd.bfloat16()                       # what gn_bwd(want16) hands over: round to nearest even
+    xr = _r16(x).requires_grad_(True)
+    (gx,) = torch.autograd.grad(F.conv2d(xr, _r16(w), None, 1, 1), xr, _r16(dy))
+    # dgrad: fp32 dy vs bf16 image -> the same numbers (the kernel rounds the fp32 dy exactly like .bfloat16())
+    d32 = ops.conv_dgrad(dyd, wd, "c3", (H, W))
+    d16 = ops.conv_dgrad(dy16, wd, "c3", (H, W))
+    assert d32.dtype == torch.float32 and d16.dtype == torch.float32
+    wide = B * (H // 8) * (W // 32) * ((Ci + 127) // 128) >= 192 and H % 8 == 0  # the image goes to the wide-tile kernel there:
+    assert torch.equal(d32, d16) if not wide else _rel(d16, d32) < 1e-5          # same sums in another order
+    assert _rel(_nchw(d32), gx) < 2e-5 and _rel(_nchw(d16), gx) < 2e-5
+    # bf16 output: the fp32 result rounded once
+    o16 = ops.conv_dgrad(dy16, wd, "c3", (H, W), out_bf16=True)
+    assert o16.dtype == torch.bfloat16 and torch.equal(o16, d16.bfloat16())
+    # an fp32 tensor carrying the image uses it too
+    dyd2 = dyd.clone()
+    dyd2._b16 = dy16
+    assert torch.equal(ops.conv_dgrad(dyd2, wd, "c3", (H, W)), d16)
+    # wgrad from the image: the weight gradient is bitwise the fp32-dy result; the bias gradient sums the ROUNDED values
+    wr = w.clone().requires_grad_(True)
+    F.conv2d(_r16(x), wr, None, 1, 1).backward(_r16(dy))
+    gw = [torch.empty_like(wd.permute(0, 2, 3, 1).contiguous()).permute(0, 3, 1, 2) for _ in range(2)]
+    gb = [torch.empty(Co, device="cuda") for _ in range(2)]
+    ops.conv_wgrad(dyd, _nhwc(x), "c3", gw[0], gb[0])
+    ops.conv_wgrad(dy16, _nhwc(x), "c3", gw[1], gb[1])
+    assert torch.equal(gw[0], gw[1]) and _rel(gw[1].cpu(), wr.grad) < 3e-5
+    assert _rel(gb[1].cpu(), _r16(dy).sum(dim=(0, 2, 3))) < 3e-5 and _rel(gb[0].cpu(), dy.sum(dim=(0, 2, 3))) < 3e-5
+    # a bf16-only gradient must not reach a layer whose kernels need fp32
+    with pytest.raises(ValueError):
+        ops.conv_dgrad(torch.zeros(1, 5, 7, 128, device="cuda", dtype=torch.bfloat16), wd if Co == 128 else _to_dev_ohwi(torch.randn(128, Ci, 3, 3)), "c3", (5, 7))
+
+
+@pytest.mark.parametrize("C,H,W,silu,B", [(128, 16, 16, True, 2), (256, 8, 32, True, 3), (512, 6, 10, False, 1)])
+def test_bf16_gradient_images_groupnorm_backward(cuda, C, H, W, silu, B):
+    from vaehip import ops
+    gen = torch.Generator().manual_seed(13 + C)
+    x = torch.randn(B, C, H, W, generator=gen) * 1.3 + 0.2
+    g = torch.randn(B, C, H, W, generator=gen)
+    add = torch.randn(B, C, H, W, generator=gen)
+    gamma, beta = 1 + 0.3 * torch.randn(C, generator=gen), 0.2 * torch.randn(C, generator=gen)
+    xd, gd, ad = _nhwc(x), _nhwc(g), _nhwc(add)
+    st = ops.gn_stats(xd, gamma.cuda(), beta.cuda())
+    dg, db = [torch.empty(C, device="cuda") for _ in range(3)], [torch.empty(C, device="cuda") for _ in range(3)]
+    g16 = gd.bfloat16()
+    ref = ops.gn_bwd(xd, g16.float(), st, gamma.cuda(), beta.cuda(), silu, ad, dg[0], db[0])     # fp32 path on the rounded g
+    both = ops.gn_bwd(xd, g16, st, gamma.cuda(), beta.cuda(), silu, ad, dg[1], db[1], want32=True, want16=True)
+    only = ops.gn_bwd(xd, g16, st, gamma.cuda(), beta.cuda(), silu, ad, dg[2], db[2], want32=False, want16=True)
+    assert both.dtype == torch.float32 and torch.equal(both, ref) and torch.equal(dg[1], dg[0]) and torch.equal(db[1], db[0])
+    assert both._b16.dtype == torch.bfloat16 and torch.equal(both._b16, ref.bfloat16())
+    assert only.dtype == torch.bfloat16 and torch.equal(only, ref.bfloat16()) and torch.equal(dg[2], dg[0])
+    # and against autograd on the rounded g
+    xr = x.clone().requires_grad_(True)
+    gm, bt = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y = F.group_norm(xr, 32, gm, bt, 1e-6)
+    (F.silu(y) if silu else y).backward(_r16(g))
+    assert _rel(_nchw(ref), xr.grad + add) < 3e-5 and _rel(dg[0].cpu(), gm.grad) < 3e-5 and _rel(db[0].cpu(), bt.grad) < 3e-5
+
+
+# ---------------------------------------------------------------------------------------------------------
+# wide-tile bf16 kernel (csrc/conv3_wide_bf16.hip): forward from an activation image, dgrad from a gradient image; shapes
+# with >= 192 tiles of 8 x 32 pixels x 128 channels.  (5,128,128,...): 320 tiles on 256 persistent workgroups (the cross-tile
+# pipeline runs), (3,64,64,256,512): 4 channel tiles per pixel tile, (7,40,96,...): rows not a multiple of 16, N tail-free
+# ---------------------------------------------------------------------------------------------------------
+WIDE_CASES = [(5, 128, 128, 128, 128), (3, 64, 64, 256, 512), (7, 40, 96, 128, 256), (2, 256, 256, 128, 128), (13, 32, 32, 512, 512)]
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co", WIDE_CASES)
+def test_bf16_wide_tile_kernel(cuda, bf16_mode, packed_weights, B, H, W, Ci, Co):
+    from vaehip import ops
+    gen = torch.Generator().manual_seed(17 + Ci + Co + H)
+    x = torch.randn(B, Ci, H, W, generator=gen) * 1.3 + 0.2
+    gamma, beta = 1 + 0.3 * torch.randn(Ci, generator=gen), 0.2 * torch.randn(Ci, generator=gen)
+    w = torch.randn(Co, Ci, 3, 3, generator=gen) / math.sqrt(9 * Ci)
+    bias = torch.randn(Co, generator=gen)
+    res = torch.randn(B, Co, H, W, generator=gen)
+    xd = _nhwc(x)
+    st = ops.gn_stats(xd, gamma.cuda(), beta.cuda())
+    wd = packed_weights(_to_dev_ohwi(w))
+    a16 = ops.gn_apply_bf16(xd, st, ops.XF_AFFINE_SILU)
+    prof = ops.PROFILER = ops.LaunchProfiler()
+    try:
+        y = ops.conv_fwd(xd, wd, bias.cuda(), "c3", xf=ops.XF_AFFINE_SILU, stats=st, res=_nhwc(res), a16=a16, gstat_groups=32)
+        dy = torch.randn(B, Co, H, W, generator=gen)
+        dy16 = _nhwc(dy).bfloat16()
+        dx = ops.conv_dgrad(dy16, wd, "c3", (H, W))
+        dx16 = ops.conv_dgrad(dy16, wd, "c3", (H, W), out_bf16=True)
+    finally:
+        ops.PROFILER = None
+    names = [r[0] for r in prof.records]
+    # the dgrad's channel tiles are over Ci: it needs its own >= 192 tiles to run on the wide kernel
+    dg = "conv3_wide_bf16_kernel<true>" if B * (H // 8) * (W // 32) * ((Ci + 127) // 128) >= 192 else "conv3_tile_bf16_kernel<true,false,0,true>"
+    assert names == ["conv3_wide_bf16_kernel<false>", dg, dg], names
+    act = a16.float().permute(0, 3, 1, 2).cpu()            # the image the kernel read: exact bf16 values
+    y_ref = F.conv2d(act, _r16(w), bias, 1, 1) + res
+    assert _rel(_nchw(y), y_ref) < 2e-5
+    # GroupNorm statistics of the output from the epilogue == statistics of the tensor it wrote
+    g2, b2 = torch.ones(Co, device="cuda"), torch.zeros(Co, device="cuda")
+    assert hasattr(y, "_gstat") and y._gstat[2] == (H // 8) * (W // 32)
+    st_f = ops.gn_stats(y, g2, b2)
+    st_p = ops.gn_stats(y.clone(), g2, b2)
+    assert _rel(st_f.mean, st_p.mean) < 1e-5 and _rel(st_f.rstd, st_p.rstd) < 1e-5
+    xr = torch.zeros(B, Ci, H, W).requires_grad_(True)
+    (gx,) = torch.autograd.grad(F.conv2d(xr, _r16(w), None, 1, 1), xr, dy16.float().permute(0, 3, 1, 2).cpu())
+    assert dx.dtype == torch.float32 and _rel(_nchw(dx), gx) < 2e-5
+    assert dx16.dtype == torch.bfloat16 and torch.equal(dx16, dx.bfloat16())
+    # the 128-pixel kernel computes the same sums in another order
+    os.environ["VAEHIP_NO_WIDE"] = "1"
+    try:
+        y2 = ops.conv_fwd(xd, wd, bias.cuda(), "c3", xf=ops.XF_AFFINE_SILU, stats=st, res=_nhwc(res), a16=a16)
+        dx2 = ops.conv_dgrad(dy16, wd, "c3", (H, W))
+    finally:
+        del os.environ["VAEHIP_NO_WIDE"]
+    assert _rel(y2, y) < 1e-5 and _rel(dx2, dx) < 1e-5
+
+
+@pytest.mark.parametrize("ratio", [30.0, 1000.0])
+def test_groupnorm_statistics_with_large_mean(cuda, ratio):
+    """|mean| / std of 30 (plausible for conv outputs of a trained VAE) and 1000: E[x^2] - mean^2 in fp32 would lose
+    ratio^2 * 1e-7 of the variance (10 % at 1000); the centred-moment statistics (streaming pass AND conv epilogue) stay at
+    fp32 accuracy against a float64 computation."""
+    from vaehip import ops
+    gen = torch.Generator().manual_seed(31)
+    B, C, H, W = 2, 128, 32, 32
+    x = torch.randn(B, C, H, W, generator=gen) + ratio * (1 + 0.1 * torch.randn(1, C, 1, 1, generator=gen))
+    gamma, beta = torch.ones(C), torch.zeros(C)
+    xd = _nhwc(x)
+    st = ops.gn_stats(xd, gamma.cuda(), beta.cuda())
+    xg = x.double().view(B, 32, -1)
+    mean64, var64 = xg.mean(-1), xg.var(-1, unbiased=False)
+    rstd64 = 1.0 / torch.sqrt(var64 + 1e-6)
+    assert _rel(st.mean, mean64) < 1e-6
+    assert float(((st.rstd.cpu().double() - rstd64) / rstd64).abs().max()) < 2e-5
+    # the normalised tensor (what the next conv sees) against float64
+    y = ops.gn_apply(xd, st, ops.XF_AFFINE)
+    ref = ((xg - mean64[..., None]) * rstd64[..., None]).view(B, C, H, W)
+    assert float((_nchw(y).double() - ref).abs().max()) < 3e-4 * max(1.0, ratio / 30)  # fp32 x itself carries ratio * 6e-8
+    # the conv epilogue: a 1-tap-dominated conv whose output keeps the large mean (bias)
+    w = torch.randn(C, C, 3, 3, generator=gen) / math.sqrt(9 * C)
+    bias = torch.full((C,), ratio) * (1 + 0.1 * torch.randn(C, generator=gen))
+    z = ops.conv_fwd(_nhwc(torch.randn(B, C, H, W, generator=gen)), _to_dev_ohwi(w), bias.cuda(), "c3", gstat_groups=32)
+    assert hasattr(z, "_gstat")
+    st_f = ops.gn_stats(z, gamma.cuda(), beta.cuda())
+    zg = _nchw(z).double().reshape(B, 32, -1)
+    r64 = 1.0 / torch.sqrt(zg.var(-1, unbiased=False) + 1e-6)
+    assert float(((st_f.rstd.cpu().double() - r64) / r64).abs().max()) < 2e-5
+    assert _rel(st_f.mean, zg.mean(-1)) < 1e-6

@@ -77,6 +77,40 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // ---------------------------------------------------------------------------------------
+// GroupNorm statistics as (mean, M2 = sum of squared deviations) per chunk, merged with Chan's formula.  Sums of x and x^2
+// cancel catastrophically once |mean| >> std (var = E[x^2] - mean^2 loses |mean/std|^2 * 1e-7 of relative accuracy in
+// fp32); torch's CPU group_norm the reference runs on is a Welford pass.  Every producer (the streaming pass and the conv
+// epilogues) therefore leaves centred moments, and the final pass merges them in fp64.
+// ---------------------------------------------------------------------------------------
+struct MeanM2 { float m, M2; };
+// two sets of n_each elements each
+__device__ __forceinline__ MeanM2 mm2_merge_equal(MeanM2 a, MeanM2 b, float n_each) {
+  const float d = b.m - a.m;
+  return MeanM2{a.m + 0.5f * d, a.M2 + b.M2 + d * d * (0.5f * n_each)};
+}
+// set a of na elements with set b of nb elements (na + nb > 0)
+__device__ __forceinline__ MeanM2 mm2_merge(MeanM2 a, float na, MeanM2 b, float nb) {
+  const float n = na + nb, d = b.m - a.m;
+  return MeanM2{a.m + d * (nb / n), a.M2 + b.M2 + d * d * (na * nb / n)};
+}
+// a lane's shifted sums (pivot pv, s1 = sum(v - pv), s2 = sum((v - pv)^2) over n values) -> centred moments
+__device__ __forceinline__ MeanM2 mm2_from_shifted(float pv, float s1, float s2, float n) {
+  const float dm = s1 / n;
+  return MeanM2{pv + dm, fmaxf(s2 - s1 * dm, 0.f)};
+}
+// merge over the `cpg` adjacent lanes of a group and the two lane halves (each lane starts with n0 elements)
+__device__ __forceinline__ MeanM2 mm2_wave_group(MeanM2 a, int cpg, float n0) {
+  float n = n0;
+  for (int o = 1; o < cpg; o <<= 1) {
+    MeanM2 b{__shfl_xor(a.m, o, 64), __shfl_xor(a.M2, o, 64)};
+    a = mm2_merge_equal(a, b, n);
+    n *= 2.f;
+  }
+  MeanM2 b{__shfl_xor(a.m, 32, 64), __shfl_xor(a.M2, 32, 64)};
+  return mm2_merge_equal(a, b, n);
+}
+
+// ---------------------------------------------------------------------------------------
 // operand staging helpers shared by the contraction kernels
 // ---------------------------------------------------------------------------------------
 constexpr int SS_HALF = 512;  // floats of GroupNorm scale (and of shift) kept in LDS per workgroup

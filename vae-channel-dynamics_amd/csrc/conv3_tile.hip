@@ -214,7 +214,7 @@ __global__ __launch_bounds__(NT) void conv3_tile_kernel(vae_igemm_args p, int ti
   const size_t obytes = (size_t)(g.Ho * cs) * (g.Wo * cs) * p.ldc * 4u;
   const auto rsC = VAE_BUF_RSRC(p.C + (int64_t)b * (g.Ho * cs) * (g.Wo * cs) * p.ldc, obytes);
   const auto rsR = VAE_BUF_RSRC((p.res ? p.res : p.C) + (int64_t)b * (g.Ho * cs) * (g.Wo * cs) * p.ldc, obytes);
-  float tsum[2] = {0.f, 0.f}, gs1[2] = {0.f, 0.f}, gs2[2] = {0.f, 0.f};
+  float tsum[2] = {0.f, 0.f}, gs1[2] = {0.f, 0.f}, gs2[2] = {0.f, 0.f}, gpv[2] = {0.f, 0.f};  // shifted sums around the lane's first value
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
     const int col = n0 + wn * 64 + ni * 32 + lr;
@@ -237,37 +237,33 @@ __global__ __launch_bounds__(NT) void conv3_tile_kernel(vae_igemm_args p, int ti
       const float v = p.alpha * acc[ni][r] + bv + rv[r];
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, off[r], 0, 0);
       tsum[ni] += (off[r] != BUF_OOB) ? fabsf(v) : 0.f;
-      if (off[r] != BUF_OOB) {
-        gs1[ni] += v;
-        gs2[ni] += v * v;
-      }
+      if (r == 0) gpv[ni] = v;
+      const float dv = v - gpv[ni];  // the statistics epilogue only runs on full tiles (every element valid)
+      gs1[ni] += dv;
+      gs2[ni] += dv * dv;
     }
   }
-  if (p.gstat) {  // uniform: GroupNorm partial sums of this tile's outputs (layout of vae_gn_stats_partial)
+  if (p.gstat) {  // uniform: centred moments (mean, M2) of this tile's outputs per group (layout of vae_gn_stats_partial)
     const int cpg = p.N / p.gstat_groups, gpt = BN / cpg;  // channels per group (4, 8 or 16), groups per 128-channel tile
     float* red2 = smem + 4 * BN;                           // [4 rows][gpt][2], behind the tracker scratch
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
-      float a1 = gs1[ni], a2 = gs2[ni];
-      for (int o = 1; o < cpg; o <<= 1) {  // the cpg lanes of a group are adjacent
-        a1 += __shfl_xor(a1, o, 64);
-        a2 += __shfl_xor(a2, o, 64);
-      }
-      a1 += __shfl_xor(a1, 32, 64);
-      a2 += __shfl_xor(a2, 32, 64);
+      const MeanM2 a = mm2_wave_group(mm2_from_shifted(gpv[ni], gs1[ni], gs2[ni], 16.f), cpg, 16.f);
       if (lh == 0 && (lr & (cpg - 1)) == 0) {
         const int gl = (wn * 64 + ni * 32 + lr) / cpg;
-        red2[(wm * gpt + gl) * 2] = a1;
-        red2[(wm * gpt + gl) * 2 + 1] = a2;
+        red2[(wm * gpt + gl) * 2] = a.m;
+        red2[(wm * gpt + gl) * 2 + 1] = a.M2;
       }
     }
     __syncthreads();
-    if (tid < gpt) {
-      const float s1 = (red2[tid * 2] + red2[(gpt + tid) * 2]) + (red2[(2 * gpt + tid) * 2] + red2[(3 * gpt + tid) * 2]);
-      const float s2 = (red2[tid * 2 + 1] + red2[(gpt + tid) * 2 + 1]) + (red2[(2 * gpt + tid) * 2 + 1] + red2[(3 * gpt + tid) * 2 + 1]);
+    if (tid < gpt) {  // the 4 rows of the tile, fixed order; each holds 32 pixels x cpg channels
+      const float nrow = 32.f * (float)cpg;
+      MeanM2 a{red2[tid * 2], red2[tid * 2 + 1]};
+#pragma unroll
+      for (int rr = 1; rr < 4; ++rr) a = mm2_merge(a, nrow * (float)rr, MeanM2{red2[(rr * gpt + tid) * 2], red2[(rr * gpt + tid) * 2 + 1]}, nrow);
       float* o = p.gstat + (((int64_t)b * (tiles_x * tiles_y) + ty * tiles_x + tx) * p.gstat_groups + n0 / cpg + tid) * 2;
-      o[0] = s1;
-      o[1] = s2;
+      o[0] = a.m;
+      o[1] = a.M2;
     }
     __syncthreads();
   }

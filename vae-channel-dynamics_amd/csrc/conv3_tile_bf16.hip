@@ -318,6 +318,7 @@ __global__ __launch_bounds__(NT, 2) void conv3_tile_bf16_kernel(vae_igemm_args p
     const auto rsC = VAE_BUF_RSRC(p.C + (int64_t)cur.b * (g.Ho * cs) * (g.Wo * cs) * p.ldc, obytes);
     const auto rsR = VAE_BUF_RSRC((p.res ? p.res : p.C) + (int64_t)cur.b * (g.Ho * cs) * (g.Wo * cs) * p.ldc, obytes);
     float tsum[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, gs1[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, gs2[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    float gpv[2][2] = {{0.f, 0.f}, {0.f, 0.f}};  // statistics as shifted sums around the lane's first value
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
       const int oy = cur.y0 + 2 * wm + mi;
@@ -325,6 +326,27 @@ __global__ __launch_bounds__(NT, 2) void conv3_tile_bf16_kernel(vae_igemm_args p
       for (int ni = 0; ni < 2; ++ni) {
         const int col = cur.n0 + wn * 64 + ni * 32 + lr;
         const bool colok = col < p.N && oy < g.Ho;
+        if (p.out_bf16) {  // uniform: bf16 output (dgrad of bf16 mode; no bias / residual / statistics).  Adjacent lanes hold
+          // adjacent channels of the same pixels: they swap every other register, so each lane stores two channels of one pixel (4 B)
+          const auto rsC16 = VAE_BUF_RSRC(reinterpret_cast<u16*>(p.C) + (int64_t)cur.b * (g.Ho * cs) * (g.Wo * cs) * p.ldc, obytes / 2);
+          const bool odd = lr & 1;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float a0 = p.alpha * acc[mi][ni][2 * j], a1 = p.alpha * acc[mi][ni][2 * j + 1];
+            const float recv = __shfl_xor(odd ? a0 : a1, 1, 64);
+            typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+            bf16x2_t h;
+            h[0] = (__bf16)(odd ? recv : a0);
+            h[1] = (__bf16)(odd ? a1 : recv);
+            const int rr = 2 * j + (odd ? 1 : 0);
+            const int ox = cur.x0 + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
+            const unsigned o16 = (colok && ox < g.Wo) ? (unsigned)((((oy * cs + (PHASE ? p.c_oy : 0)) * (g.Wo * cs) + ox * cs + (PHASE ? p.c_ox : 0)) * p.ldc + (col & ~1)) * 2) : BUF_OOB;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, h), rsC16, o16, 0, 0);
+            acc[mi][ni][2 * j] = 0.f;
+            acc[mi][ni][2 * j + 1] = 0.f;
+          }
+          continue;
+        }
         const float bv = (p.bias && colok) ? p.bias[col] : 0.f;
         unsigned off[16];
         float rv[16];
@@ -343,10 +365,10 @@ __global__ __launch_bounds__(NT, 2) void conv3_tile_bf16_kernel(vae_igemm_args p
           const float v = p.alpha * acc[mi][ni][r] + bv + rv[r];
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, off[r], 0, 0);
           tsum[mi][ni] += (off[r] != BUF_OOB) ? fabsf(v) : 0.f;
-          if (off[r] != BUF_OOB) {
-            gs1[mi][ni] += v;
-            gs2[mi][ni] += v * v;
-          }
+          if (r == 0) gpv[mi][ni] = v;
+          const float dv = v - gpv[mi][ni];  // (the statistics epilogue only runs on full tiles)
+          gs1[mi][ni] += dv;
+          gs2[mi][ni] += dv * dv;
           acc[mi][ni][r] = 0.f;
         }
       }
@@ -358,27 +380,23 @@ __global__ __launch_bounds__(NT, 2) void conv3_tile_bf16_kernel(vae_igemm_args p
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
-          float a1 = gs1[mi][ni], a2 = gs2[mi][ni];
-          for (int o = 1; o < cpg; o <<= 1) {  // the cpg lanes of a group are adjacent
-            a1 += __shfl_xor(a1, o, 64);
-            a2 += __shfl_xor(a2, o, 64);
-          }
-          a1 += __shfl_xor(a1, 32, 64);
-          a2 += __shfl_xor(a2, 32, 64);
+          const MeanM2 a = mm2_wave_group(mm2_from_shifted(gpv[mi][ni], gs1[mi][ni], gs2[mi][ni], 16.f), cpg, 16.f);
           if (lh == 0 && (lr & (cpg - 1)) == 0) {
             const int gl = (wn * 64 + ni * 32 + lr) / cpg;
-            red2[((2 * wm + mi) * gpt + gl) * 2] = a1;
-            red2[((2 * wm + mi) * gpt + gl) * 2 + 1] = a2;
+            red2[((2 * wm + mi) * gpt + gl) * 2] = a.m;
+            red2[((2 * wm + mi) * gpt + gl) * 2 + 1] = a.M2;
           }
         }
       __syncthreads();
-      if (tid < gpt) {
-        const float s1 = (red2[tid * 2] + red2[(gpt + tid) * 2]) + (red2[(2 * gpt + tid) * 2] + red2[(3 * gpt + tid) * 2]);
-        const float s2 = (red2[tid * 2 + 1] + red2[(gpt + tid) * 2 + 1]) + (red2[(2 * gpt + tid) * 2 + 1] + red2[(3 * gpt + tid) * 2 + 1]);
+      if (tid < gpt) {  // the 4 rows of the tile, fixed order; each holds 32 pixels x cpg channels
+        const float nrow = 32.f * (float)cpg;
+        MeanM2 a{red2[tid * 2], red2[tid * 2 + 1]};
+#pragma unroll
+        for (int rr = 1; rr < 4; ++rr) a = mm2_merge(a, nrow * (float)rr, MeanM2{red2[(rr * gpt + tid) * 2], red2[(rr * gpt + tid) * 2 + 1]}, nrow);
         const int tile_in_img = cur.lin - cur.b * (tiles_x * tiles_y);
         float* o = p.gstat + (((int64_t)cur.b * (tiles_x * tiles_y) + tile_in_img) * p.gstat_groups + cur.n0 / cpg + tid) * 2;
-        o[0] = s1;
-        o[1] = s2;
+        o[0] = a.m;
+        o[1] = a.M2;
       }
       __syncthreads();
     }

@@ -326,39 +326,76 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 }
 
 // ---------------- dead-weight scan ----------------
-__global__ __launch_bounds__(256) void dead_scan_kernel(const float* __restrict__ w, const int64_t* __restrict__ seg_off, float thr,
-                                                        unsigned long long* __restrict__ counts, double* __restrict__ abssum) {
-  __shared__ double red[4];
-  const int s = blockIdx.x;
-  const int64_t b = seg_off[2 * s], e = seg_off[2 * s + 1];
-  double sum = 0.0, cnt = 0.0;
-  for (int64_t i = b + threadIdx.x; i < e; i += 256) {
-    const float a = fabsf(w[i]);
-    sum += (double)a;
-    cnt += (a < thr) ? 1.0 : 0.0;
+// One launch over every parameter segment: the segments are cut into chunks of DEAD_CHUNK elements, one workgroup per chunk
+// (a 2.4 M-element conv weight is 72 chunks; one workgroup per SEGMENT left 36 large segments on 36 CUs), and a second
+// small kernel adds each segment's chunk partials in chunk order (fixed order: reproducible counts AND sums).
+// seg_chunk0 [nseg+1]: prefix sum of ceil(len/DEAD_CHUNK) (host); a workgroup finds its segment by bisection.
+constexpr int DEAD_CHUNK = 32768;
+
+__device__ __forceinline__ int dead_find_segment(const int32_t* __restrict__ seg_chunk0, int nseg, int chunk) {
+  int lo = 0, hi = nseg;  // seg_chunk0[lo] <= chunk < seg_chunk0[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (seg_chunk0[mid] <= chunk) lo = mid; else hi = mid;
   }
-  sum = block_sum_d(sum, red);
-  cnt = block_sum_d(cnt, red);
+  return lo;
+}
+
+// ADAPT: count |w| < athr[seg] (and < thr when use_fixed) instead of |w| < thr, no sum
+template <bool ADAPT>
+__global__ __launch_bounds__(256) void dead_scan_chunk_kernel(const float* __restrict__ w, const int64_t* __restrict__ seg_off,
+                                                              const int32_t* __restrict__ seg_chunk0, int nseg, float thr, int use_fixed,
+                                                              const float* __restrict__ athr, unsigned long long* __restrict__ pcnt,
+                                                              double* __restrict__ psum) {
+  __shared__ double red[4];
+  const int chunk = blockIdx.x;
+  const int s = dead_find_segment(seg_chunk0, nseg, chunk);
+  const int64_t b = seg_off[2 * s] + (int64_t)(chunk - seg_chunk0[s]) * DEAD_CHUNK;
+  const int64_t e = min(seg_off[2 * s + 1], b + DEAD_CHUNK);
+  const float at = ADAPT ? athr[s] : 0.f;
+  double sum = 0.0;
+  unsigned cnt = 0;
+  // segment starts are 32-byte aligned in the arena and DEAD_CHUNK is a multiple of 4: float4 body, scalar tail
+  const int64_t n4 = (e - b) >> 2;
+  const f32x4* w4 = reinterpret_cast<const f32x4*>(w + b);
+  const bool vec = ((reinterpret_cast<uintptr_t>(w + b)) & 15u) == 0;
+  if (vec) {
+    for (int64_t i = threadIdx.x; i < n4; i += 256) {
+      const f32x4 v = w4[i];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float a = fabsf(v[k]);
+        if (ADAPT) cnt += ((a < at) && (!use_fixed || a < thr)) ? 1u : 0u;
+        else { cnt += (a < thr) ? 1u : 0u; sum += (double)a; }
+      }
+    }
+  }
+  for (int64_t i = b + (vec ? (n4 << 2) : 0) + threadIdx.x; i < e; i += 256) {
+    const float a = fabsf(w[i]);
+    if (ADAPT) cnt += ((a < at) && (!use_fixed || a < thr)) ? 1u : 0u;
+    else { cnt += (a < thr) ? 1u : 0u; sum += (double)a; }
+  }
+  const double c = block_sum_d((double)cnt, red);  // exact: counts are far below 2^53
+  if (!ADAPT) sum = block_sum_d(sum, red);
   if (threadIdx.x == 0) {
-    counts[s] = (unsigned long long)(cnt + 0.5);
-    abssum[s] = sum;
+    pcnt[chunk] = (unsigned long long)(c + 0.5);
+    if (!ADAPT) psum[chunk] = sum;
   }
 }
-__global__ __launch_bounds__(256) void dead_scan_adaptive_kernel(const float* __restrict__ w, const int64_t* __restrict__ seg_off,
-                                                                 float thr, int use_fixed, const float* __restrict__ athr,
-                                                                 unsigned long long* __restrict__ counts) {
-  __shared__ double red[4];
+
+__global__ __launch_bounds__(64) void dead_scan_final_kernel(const int32_t* __restrict__ seg_chunk0, const unsigned long long* __restrict__ pcnt,
+                                                             const double* __restrict__ psum, unsigned long long* __restrict__ counts,
+                                                             double* __restrict__ abssum) {
   const int s = blockIdx.x;
-  const int64_t b = seg_off[2 * s], e = seg_off[2 * s + 1];
-  const float at = athr[s];
-  double cnt = 0.0;
-  for (int64_t i = b + threadIdx.x; i < e; i += 256) {
-    const float a = fabsf(w[i]);
-    const bool c = (a < at) && (!use_fixed || a < thr);
-    cnt += c ? 1.0 : 0.0;
+  if (threadIdx.x != 0) return;
+  unsigned long long c = 0;
+  double sum = 0.0;
+  for (int k = seg_chunk0[s]; k < seg_chunk0[s + 1]; ++k) {  // chunk order
+    c += pcnt[k];
+    if (psum) sum += psum[k];
   }
-  cnt = block_sum_d(cnt, red);
-  if (threadIdx.x == 0) counts[s] = (unsigned long long)(cnt + 0.5);
+  counts[s] = c;
+  if (abssum) abssum[s] = sum;
 }
 
 }  // namespace
@@ -500,18 +537,28 @@ extern "C" int vae_adamw(float* p, const float* g, float* m, float* v, int64_t n
   return VAE_OK;
 }
 
-extern "C" int vae_dead_scan(const float* w, const int64_t* seg_off, int32_t nseg, float thr, unsigned long long* out_counts,
+extern "C" int vae_dead_scan_chunk(void) { return DEAD_CHUNK; }
+
+extern "C" int vae_dead_scan(const float* w, const int64_t* seg_off, const int32_t* seg_chunk0, int32_t nseg, int32_t nchunk, float thr,
+                             unsigned long long* part_counts, double* part_abssum, unsigned long long* out_counts,
                              double* out_abssum, void* stream) {
-  VAE_CHECK(w && seg_off && out_counts && out_abssum && nseg > 0, "dead_scan: bad args");
-  hipLaunchKernelGGL(dead_scan_kernel, dim3(nseg), dim3(256), 0, (hipStream_t)stream, w, seg_off, thr, out_counts, out_abssum);
+  VAE_CHECK(w && seg_off && seg_chunk0 && part_counts && part_abssum && out_counts && out_abssum && nseg > 0 && nchunk >= nseg,
+            "dead_scan: bad args");
+  hipLaunchKernelGGL(dead_scan_chunk_kernel<false>, dim3(nchunk), dim3(256), 0, (hipStream_t)stream, w, seg_off, seg_chunk0, nseg, thr, 0,
+                     (const float*)nullptr, part_counts, part_abssum);
+  hipLaunchKernelGGL(dead_scan_final_kernel, dim3(nseg), dim3(64), 0, (hipStream_t)stream, seg_chunk0, part_counts,
+                     (const double*)part_abssum, out_counts, out_abssum);
   VAE_LAUNCH_CHECK("dead_scan");
   return VAE_OK;
 }
-extern "C" int vae_dead_scan_adaptive(const float* w, const int64_t* seg_off, int32_t nseg, float thr, int32_t use_fixed,
-                                      const float* adaptive_thr, unsigned long long* out_counts, void* stream) {
-  VAE_CHECK(w && seg_off && out_counts && adaptive_thr && nseg > 0, "dead_scan_adaptive: bad args");
-  hipLaunchKernelGGL(dead_scan_adaptive_kernel, dim3(nseg), dim3(256), 0, (hipStream_t)stream, w, seg_off, thr, use_fixed,
-                     adaptive_thr, out_counts);
+extern "C" int vae_dead_scan_adaptive(const float* w, const int64_t* seg_off, const int32_t* seg_chunk0, int32_t nseg, int32_t nchunk,
+                                      float thr, int32_t use_fixed, const float* adaptive_thr, unsigned long long* part_counts,
+                                      unsigned long long* out_counts, void* stream) {
+  VAE_CHECK(w && seg_off && seg_chunk0 && part_counts && out_counts && adaptive_thr && nseg > 0 && nchunk >= nseg, "dead_scan_adaptive: bad args");
+  hipLaunchKernelGGL(dead_scan_chunk_kernel<true>, dim3(nchunk), dim3(256), 0, (hipStream_t)stream, w, seg_off, seg_chunk0, nseg, thr,
+                     use_fixed, adaptive_thr, part_counts, (double*)nullptr);
+  hipLaunchKernelGGL(dead_scan_final_kernel, dim3(nseg), dim3(64), 0, (hipStream_t)stream, seg_chunk0, part_counts,
+                     (const double*)nullptr, out_counts, (double*)nullptr);
   VAE_LAUNCH_CHECK("dead_scan_adaptive");
   return VAE_OK;
 }

@@ -22,6 +22,9 @@ bool conv3_tile_eligible(const vae_igemm_args& a, bool vec, bool bkm);
 int launch_conv3_tile(const vae_igemm_args& a, bool bkm, hipStream_t st);
 int launch_conv3_tile_bf16(const vae_igemm_args& a, bool bkm, hipStream_t st);
 bool conv3_tile_bf16_packed(const vae_igemm_args& a);
+bool conv3_wide_bf16_eligible(const vae_igemm_args& a);                 // conv3_wide_bf16.hip (both operands bf16 images, 8x32 tiles)
+int conv3_wide_bf16_gstat_chunks(const vae_igemm_args& a);
+int launch_conv3_wide_bf16(const vae_igemm_args& a, hipStream_t st);
 int conv3_tile_gstat_chunks(const vae_igemm_args& a);  // both tile kernels share the tile shape and the epilogue layout
 bool wgrad3_tile_eligible(const vae_wgrad_args& a, bool vec);
 int64_t wgrad3_tile_units(const vae_conv_geom& g);
@@ -534,7 +537,57 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(vae_wgrad_args p) {
   }
 }
 
-__global__ void reduce_splits_kernel(const float* __restrict__ partial, int nsplit, int64_t n, float* __restrict__ out) {
+// out[i] = sum_k partial[k][i], fixed association (reproducible).  16-byte loads, 8 independent loads in flight per
+// thread; KP threads share a column quad and split the k range (a 128-channel layer has 128 splits of only 147 K elements:
+// one thread per element leaves too few bytes in flight to fill HBM), combined through LDS in k order.
+// A second, small reduction (the bias gradient: [nsplit][n2]) rides in the same launch: workgroups main_blocks.. do it.
+template <int KP>
+__global__ __launch_bounds__(256) void reduce_splits_kernel(const float* __restrict__ partial, int nsplit, int64_t n, float* __restrict__ out,
+                                                            int main_blocks, const float* __restrict__ partial2, int n2, float* __restrict__ out2) {
+  constexpr int COLS = 256 / KP;
+  __shared__ f32x4 red[KP > 1 ? 256 : 1];
+  if ((int)blockIdx.x >= main_blocks) {  // uniform per workgroup
+    const int i = ((int)blockIdx.x - main_blocks) * 256 + threadIdx.x;
+    if (i < n2) {
+      float s2 = 0.f;
+      for (int k = 0; k < nsplit; ++k) s2 += partial2[(int64_t)k * n2 + i];
+      out2[i] = s2;
+    }
+    return;
+  }
+  const int col = threadIdx.x % COLS, kp = threadIdx.x / COLS;
+  const int64_t n4 = n >> 2;
+  const int per = (nsplit + KP - 1) / KP;
+  const int k0 = kp * per, k1 = min(nsplit, k0 + per);
+  auto column = [&](int64_t i) {  // sum of splits [k0, k1) of column quad i
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    const f32x4* p = reinterpret_cast<const f32x4*>(partial) + i;
+    int k = k0;
+    for (; k + 8 <= k1; k += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = p[(int64_t)(k + j) * n4];
+      s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    for (; k < k1; ++k) s += p[(int64_t)k * n4];
+    return s;
+  };
+  if (KP == 1) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)main_blocks * 256) reinterpret_cast<f32x4*>(out)[i] = column(i);
+    return;
+  }
+  const int64_t i = (int64_t)blockIdx.x * COLS + col;  // one workgroup per COLS column quads (no loop: the barrier below is uniform)
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (i < n4) s = column(i);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (kp == 0 && i < n4) {
+#pragma unroll
+    for (int j = 1; j < KP; ++j) s += red[j * COLS + col];
+    reinterpret_cast<f32x4*>(out)[i] = s;
+  }
+}
+__global__ void reduce_splits_scalar_kernel(const float* __restrict__ partial, int nsplit, int64_t n, float* __restrict__ out) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
@@ -684,6 +737,11 @@ static bool rows_use_tile_bf16(const vae_igemm_args& a, bool vec, bool bkm) {
   return a.prec == VAE_PREC_BF16 && rows_use_tile(a, vec, bkm) && conv3_tile_bf16_packed(a);
 }
 
+// the wide-tile kernel serves a layer the 128-pixel bf16 halo-tile kernel would serve, when both operands are bf16 images
+static bool rows_use_wide_bf16(const vae_igemm_args& a, bool vec, bool bkm) {
+  return rows_use_tile_bf16(a, vec, bkm) && conv3_wide_bf16_eligible(a) && !getenv("VAEHIP_NO_WIDE");
+}
+
 // both the forward and the wgrad of this 3x3 stride-1 layer run on the bf16 halo-tile kernels (which can read a bf16
 // activation image); pointers are placeholders with the alignment the real ones must have
 extern "C" int vae_bf16_act_image_ok(const vae_conv_geom* gp, int32_t Cout, int32_t Cin) {
@@ -702,7 +760,34 @@ extern "C" int vae_bf16_act_image_ok(const vae_conv_geom* gp, int32_t Cout, int3
   return wgrad_use_tile_bf16(w) ? 1 : 0;
 }
 
+// the output gradient of this 3x3 stride-1 layer may be handed over as a bf16 image: its dgrad (A16) and its weight
+// gradient (dY16) both run on the bf16 halo-tile kernels
+extern "C" int vae_bf16_grad_image_ok(const vae_conv_geom* gp, int32_t Cout, int32_t Cin) {
+  if (!gp || getenv("VAEHIP_FLAT_CONV") || getenv("VAEHIP_NO_GRAD16")) return 0;
+  const vae_conv_geom& g = *gp;
+  if (g.mode != VAE_MODE_FWD || g.taps != 9 || g.stride != 1 || Cin % 8 != 0 || Cout % 8 != 0 || g.Ho != g.Hs || g.Wo != g.Ws) return 0;
+  static const float dummy[4] __attribute__((aligned(16))) = {0.f, 0.f, 0.f, 0.f};
+  vae_igemm_args d{};  // the dgrad launch ops.conv_dgrad builds
+  d.A = d.W = dummy; d.C = const_cast<float*>(dummy); d.Wh = dummy;
+  d.g = g; d.g.Cs = Cout; d.g.mode = VAE_MODE_DGRAD;
+  d.M = g.B * g.Ho * g.Wo; d.N = Cin; d.K = Cout; d.ldc = Cin;
+  d.sn = 1; d.sk = (int64_t)g.taps * Cin; d.st = Cin; d.batch = 1; d.alpha = 1.f; d.prec = VAE_PREC_BF16; d.xf = VAE_XF_NONE;
+  if (!rows_use_tile_bf16(d, rows_vec(d, true), true)) return 0;
+  vae_wgrad_args w{};
+  w.dY = w.X = dummy; w.g = g; w.g.Cs = Cin; w.M = Cout; w.N = Cin; w.ldy = Cout; w.npix = d.M; w.nsplit = 1; w.batch = 1; w.alpha = 1.f;
+  w.prec = VAE_PREC_BF16; w.xf = VAE_XF_NONE;
+  return wgrad_use_tile_bf16(w) ? 1 : 0;
+}
+
 static bool rows_is_phase(const vae_igemm_args& a) { return a.tapmask != 0 || a.a_step > 1 || a.c_step > 1; }
+extern "C" int vae_conv_out_bf16_ok(const vae_igemm_args* ap) {
+  if (!ap) return 0;
+  const vae_igemm_args& a = *ap;
+  const bool bkm = rows_bkm(a), vec = rows_vec(a, bkm);
+  if (rows_is_phase(a) || a.bias || a.res || a.track || a.gstat || a.N % 8 != 0 || a.ldc % 2 != 0) return 0;
+  if ((a.A16 == nullptr && conv_smallk_eligible(a)) || conv_smalln_eligible(a)) return 0;
+  return rows_use_tile_bf16(a, vec, bkm) ? 1 : 0;
+}
 extern "C" int vae_conv_phase_ok(const vae_igemm_args* ap) {
   if (!ap) return 0;
   const vae_igemm_args& a = *ap;
@@ -716,6 +801,7 @@ extern "C" int vae_conv_gstat_chunks(const vae_igemm_args* ap) {
   const vae_igemm_args& a = *ap;
   const bool bkm = rows_bkm(a), vec = rows_vec(a, bkm);
   if ((a.A16 == nullptr && conv_smallk_eligible(a)) || conv_smalln_eligible(a)) return 0;
+  if (rows_use_wide_bf16(a, vec, bkm)) return conv3_wide_bf16_gstat_chunks(a);
   if (rows_use_tile_bf16(a, vec, bkm) || (a.prec != VAE_PREC_BF16 && rows_use_tile(a, vec, bkm))) return conv3_tile_gstat_chunks(a);
   return 0;
 }
@@ -735,6 +821,8 @@ extern "C" int vae_igemm_kernel_name(const vae_igemm_args* ap, char* buf, int32_
     snprintf(buf, n, "conv_smallk_kernel");
   else if (conv_smalln_eligible(a))
     snprintf(buf, n, "conv_smalln_kernel<%d>", a.xf);
+  else if (rows_use_wide_bf16(a, vec, bkm))
+    snprintf(buf, n, "conv3_wide_bf16_kernel<%s>", tf[a.g.mode == VAE_MODE_DGRAD]);
   else if (rows_use_tile_bf16(a, vec, bkm))
     snprintf(buf, n, "conv3_tile_bf16_kernel<%s,%s,%d,%s>", tf[a.g.mode == VAE_MODE_DGRAD], tf[a.g.mode == VAE_MODE_UP2X], a.xf,
              tf[a.A16 != nullptr]);
@@ -755,7 +843,7 @@ extern "C" int vae_wgrad_kernel_name(const vae_wgrad_args* ap, char* buf, int32_
   const char* tf[2] = {"false", "true"};
   if (wgrad_is_phase(a)) snprintf(buf, n, "wgrad3_tile_kernel<%s,%d>", tf[a.g.mode == VAE_MODE_UP2X], a.xf);
   else if (wgrad_smallk_kind(a)) snprintf(buf, n, "wgrad_smallk_kernel<%s,%d>", tf[wgrad_smallk_kind(a) == 1], a.xf);
-  else if (wgrad_use_tile_bf16(a)) snprintf(buf, n, "wgrad3_tile_bf16_kernel<%s,%d,%s>", tf[a.g.mode == VAE_MODE_UP2X], a.xf, tf[a.X16 != nullptr]);
+  else if (wgrad_use_tile_bf16(a)) snprintf(buf, n, "wgrad3_tile_bf16_kernel<%s,%d,%s,%s>", tf[a.g.mode == VAE_MODE_UP2X], a.xf, tf[a.X16 != nullptr], tf[a.dY16 != nullptr]);
   else if (wgrad_use_tile(a)) snprintf(buf, n, "wgrad3_tile_kernel<%s,%d>", tf[a.g.mode == VAE_MODE_UP2X], a.xf);
   else if (a.prec == VAE_PREC_BF16 && vec)
     snprintf(buf, n, "wgrad_bf16_kernel<%s,%d>", a.M <= 32 ? "32,128,1,4" : (a.N <= 32 ? "128,32,4,1" : "128,128,4,2"), a.xf);
@@ -782,6 +870,7 @@ extern "C" int vae_igemm_rows(const vae_igemm_args* ap, void* stream) {
   const bool bkm = rows_bkm(a);
   const bool vec = rows_vec(a, bkm);
   VAE_CHECK(a.gstat == nullptr || vae_conv_gstat_chunks(ap) > 0, "igemm_rows: no statistics epilogue for these arguments (vae_conv_gstat_chunks)");
+  VAE_CHECK(!a.out_bf16 || vae_conv_out_bf16_ok(ap), "igemm_rows: out_bf16 needs a bf16 halo-tile kernel and no bias / res / track / gstat (vae_conv_out_bf16_ok)");
   hipStream_t st = (hipStream_t)stream;
   if (rows_is_phase(a)) {  // sub-sampled views / tap subsets: only the fp32 halo-tile kernel implements them
     VAE_CHECK(vae_conv_phase_ok(ap), "igemm_rows: tapmask / a_step / c_step need a halo-tile kernel (vae_conv_phase_ok)");
@@ -802,6 +891,11 @@ extern "C" int vae_igemm_rows(const vae_igemm_args* ap, void* stream) {
   }
   VAE_CHECK(a.A16 == nullptr || (a.xf == VAE_XF_NONE && rows_use_tile_bf16(a, vec, bkm) && aligned16(a.A16) && a.g.Cs % 8 == 0),
             "igemm_rows: A16 needs bf16 mode, xf == NONE and a layer vae_bf16_act_image_ok accepts");
+  if (rows_use_wide_bf16(a, vec, bkm)) {
+    if (int rc2 = launch_conv3_wide_bf16(a, st)) return rc2;
+    VAE_LAUNCH_CHECK("conv3_wide_bf16");
+    return VAE_OK;
+  }
   if (rows_use_tile_bf16(a, vec, bkm)) {
     if (int rc2 = launch_conv3_tile_bf16(a, bkm, st)) return rc2;
     VAE_LAUNCH_CHECK("conv3_tile_bf16");
@@ -837,7 +931,9 @@ extern "C" int vae_wgrad(const vae_wgrad_args* ap, void* stream) {
   VAE_CHECK(ap != nullptr, "wgrad: null args");
   const vae_wgrad_args& a = *ap;
   if (int e = check_geom("wgrad", a.g)) return e;
-  VAE_CHECK(a.dY && a.X, "wgrad: null operand");
+  VAE_CHECK((a.dY || a.dY16) && a.X, "wgrad: null operand");
+  VAE_CHECK(a.dY16 == nullptr || (wgrad_use_tile_bf16(a) && !wgrad_is_phase(a) && !(a.X16 == nullptr && wgrad_smallk_kind(a)) && aligned16(a.dY16) && a.ldy % 8 == 0 && a.M % 8 == 0),
+            "wgrad: dY16 needs bf16 mode and a layer vae_bf16_grad_image_ok accepts");
   VAE_CHECK(a.M > 0 && a.N > 0 && a.npix > 0 && a.nsplit > 0 && a.batch > 0, "wgrad: bad sizes");
   VAE_CHECK(a.N <= a.g.Cs, "wgrad: N exceeds source channels");
   VAE_CHECK((int64_t)a.g.B * a.g.Ho * a.g.Wo == a.npix, "wgrad: npix != B*Ho*Wo");
@@ -896,11 +992,37 @@ extern "C" int vae_wgrad(const vae_wgrad_args* ap, void* stream) {
   return VAE_OK;
 }
 
+static int reduce_splits_impl(const float* partial, int32_t nsplit, int64_t n, float* out, const float* partial2, int32_t n2, float* out2,
+                              hipStream_t st) {
+  const int extra = partial2 ? (n2 + 255) / 256 : 0;
+  if (n % 4 == 0 && aligned16(partial) && aligned16(out)) {
+    const int64_t n4 = n / 4;
+    if (nsplit >= 32) {  // few elements, many splits: 4 threads per column quad
+      const int64_t blocks = (n4 + 63) / 64;
+      VAE_CHECK(blocks + extra < (1ll << 31), "reduce_splits: too many elements");
+      hipLaunchKernelGGL(reduce_splits_kernel<4>, dim3((unsigned)(blocks + extra)), dim3(256), 0, st, partial, nsplit, n, out, (int)blocks, partial2, n2, out2);
+    } else {
+      const int64_t blocks = std::min<int64_t>((n4 + 255) / 256, 8192);
+      hipLaunchKernelGGL(reduce_splits_kernel<1>, dim3((unsigned)(blocks + extra)), dim3(256), 0, st, partial, nsplit, n, out, (int)blocks, partial2, n2, out2);
+    }
+  } else {
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(reduce_splits_scalar_kernel, dim3(blocks), dim3(256), 0, st, partial, nsplit, n, out);
+    if (partial2) hipLaunchKernelGGL(reduce_splits_scalar_kernel, dim3(extra), dim3(256), 0, st, partial2, nsplit, (int64_t)n2, out2);
+  }
+  return 0;
+}
 extern "C" int vae_reduce_splits(const float* partial, int32_t nsplit, int64_t n, float* out, void* stream) {
   VAE_CHECK(partial && out && nsplit > 0 && n > 0, "reduce_splits: bad args");
-  int blocks = (int)((n + 255) / 256);
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(reduce_splits_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partial, nsplit, n, out);
+  if (int rc = reduce_splits_impl(partial, nsplit, n, out, nullptr, 0, nullptr, (hipStream_t)stream)) return rc;
   VAE_LAUNCH_CHECK("reduce_splits");
+  return VAE_OK;
+}
+extern "C" int vae_reduce_splits2(const float* partial, int32_t nsplit, int64_t n, float* out, const float* partial2, int32_t n2, float* out2,
+                                  void* stream) {
+  VAE_CHECK(partial && out && partial2 && out2 && nsplit > 0 && n > 0 && n2 > 0, "reduce_splits2: bad args");
+  if (int rc = reduce_splits_impl(partial, nsplit, n, out, partial2, n2, out2, (hipStream_t)stream)) return rc;
+  VAE_LAUNCH_CHECK("reduce_splits2");
   return VAE_OK;
 }

@@ -7,6 +7,27 @@
 
 namespace {
 
+// 4 consecutive elements of a gradient tensor stored as fp32 or as bf16 (bf16 mode keeps the conv dgrad outputs and the
+// GroupNorm-backward outputs that only feed convolutions as bf16: their consumers round them to bf16 anyway)
+template <bool BF>
+__device__ __forceinline__ f32x4 load4g(const void* base, int64_t idx4) {
+  if (!BF) return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + idx4 * 4);
+  const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + idx4 * 4);
+  f32x4 v;
+  v[0] = __builtin_bit_cast(float, r.x << 16);
+  v[1] = __builtin_bit_cast(float, r.x & 0xffff0000u);
+  v[2] = __builtin_bit_cast(float, r.y << 16);
+  v[3] = __builtin_bit_cast(float, r.y & 0xffff0000u);
+  return v;
+}
+__device__ __forceinline__ uint2 pack4_bf16(f32x4 v) {
+  typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+  bf16x4_t h;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) h[e] = (__bf16)v[e];
+  return __builtin_bit_cast(uint2, h);
+}
+
 // layout helper: 256 threads = PR pixel rows x Q float4 lanes (Q = C/4)
 struct Lay {
   int Q, PR, cq, pr;
@@ -22,34 +43,47 @@ __device__ __forceinline__ Lay make_lay(int C) {
 
 __global__ __launch_bounds__(256) void gn_stats_partial_kernel(const float* __restrict__ x, int HW, int C, int G,
                                                                int nchunk, float* __restrict__ ws) {
-  __shared__ float red[2][256];
+  __shared__ float red[3][256];
   const Lay l = make_lay(C);
   const int chunk = blockIdx.x, b = blockIdx.y;
   const int per = (HW + nchunk - 1) / nchunk;
   const int p0 = chunk * per, p1 = min(HW, p0 + per);
   const float* xb = x + (int64_t)b * HW * C;
-  f32x4 s = {0, 0, 0, 0}, q = {0, 0, 0, 0};
+  // shifted sums around the thread's first value (no cancellation), then centred moments, merged over the group's threads
+  float pv = 0.f, s1 = 0.f, s2 = 0.f, cnt = 0.f;
   for (int pix = p0 + l.pr; pix < p1; pix += l.PR) {
     f32x4 v = *reinterpret_cast<const f32x4*>(xb + (int64_t)pix * C + l.cq * 4);
-    s += v;
-    q += v * v;
+    if (cnt == 0.f) pv = v[0];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float d = v[e] - pv;
+      s1 += d;
+      s2 += d * d;
+    }
+    cnt += 4.f;
   }
-  red[0][threadIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
-  red[1][threadIdx.x] = (q[0] + q[1]) + (q[2] + q[3]);
+  const MeanM2 mine = (cnt > 0.f) ? mm2_from_shifted(pv, s1, s2, cnt) : MeanM2{0.f, 0.f};
+  red[0][threadIdx.x] = mine.m;
+  red[1][threadIdx.x] = mine.M2;
+  red[2][threadIdx.x] = cnt;
   __syncthreads();
   if (threadIdx.x < G) {
     const int g = threadIdx.x;
     const int lanes = (C / G) >> 2;  // float4 lanes per group
-    float ts = 0.f, tq = 0.f;
+    MeanM2 acc{0.f, 0.f};
+    float n = 0.f;
     for (int pr = 0; pr < l.PR; ++pr)
-      for (int j = 0; j < lanes; ++j) {
-        int t = pr * l.Q + g * lanes + j;
-        ts += red[0][t];
-        tq += red[1][t];
+      for (int j = 0; j < lanes; ++j) {  // fixed order
+        const int t = pr * l.Q + g * lanes + j;
+        const float nt = red[2][t];
+        if (nt > 0.f) {
+          acc = (n > 0.f) ? mm2_merge(acc, n, MeanM2{red[0][t], red[1][t]}, nt) : MeanM2{red[0][t], red[1][t]};
+          n += nt;
+        }
       }
     float* o = ws + (((int64_t)b * nchunk + chunk) * G + g) * 2;
-    o[0] = ts;
-    o[1] = tq;
+    o[0] = acc.m;
+    o[1] = acc.M2;
   }
 }
 
@@ -59,34 +93,52 @@ __global__ __launch_bounds__(256) void gn_stats_final_kernel(const float* __rest
                                                              float* __restrict__ mean, float* __restrict__ rstd,
                                                              float* __restrict__ scale, float* __restrict__ shift) {
   __shared__ float smean[64], srstd[64];
-  __shared__ double sS[256], sQ[256];
+  __shared__ double sS[256], sQ[256], sMean[64];
   const int b = blockIdx.x;
-  // the chunk range is dealt out to 256 / G threads per group (a conv epilogue leaves one chunk per output tile: hundreds),
-  // partial sums in fp64, combined in a fixed order
+  // ws[b][chunk][g] = (mean, M2) of chunk `chunk` (pixels [chunk*per, min(HW, (chunk+1)*per)) x the group's channels; a conv
+  // epilogue leaves one chunk per output tile: hundreds).  Chan's merge in fp64: first the count-weighted mean, then
+  // M2 = sum_k M2_k + n_k (mean_k - mean)^2.  The chunk range is dealt out to 256 / G threads per group, fixed order.
   const int parts = 256 / G;  // G <= 64
+  const int per = (HW + nchunk - 1) / nchunk;
+  const int cpg_ = C / G;
+  const int g_ = threadIdx.x % G, part_ = threadIdx.x / G;
   {
-    const int g = threadIdx.x % G, part = threadIdx.x / G;
-    double S = 0.0, Q = 0.0;
-    if (part < parts)
-      for (int c = part; c < nchunk; c += parts) {
-        const float* o = ws + (((int64_t)b * nchunk + c) * G + g) * 2;
-        S += (double)o[0];
-        Q += (double)o[1];
+    double S = 0.0;
+    if (part_ < parts)
+      for (int c = part_; c < nchunk; c += parts) {
+        const float* o = ws + (((int64_t)b * nchunk + c) * G + g_) * 2;
+        const double nk = (double)(min(HW, (c + 1) * per) - c * per) * (double)cpg_;
+        S += nk * (double)o[0];
       }
     sS[threadIdx.x] = S;
+  }
+  __syncthreads();
+  if (threadIdx.x < G) {
+    double S = 0.0;
+    for (int part = 0; part < parts; ++part) S += sS[part * G + threadIdx.x];
+    sMean[threadIdx.x] = S / ((double)HW * (double)cpg_);
+  }
+  __syncthreads();
+  {
+    const double m = sMean[g_];
+    double Q = 0.0;
+    if (part_ < parts)
+      for (int c = part_; c < nchunk; c += parts) {
+        const float* o = ws + (((int64_t)b * nchunk + c) * G + g_) * 2;
+        const double nk = (double)(min(HW, (c + 1) * per) - c * per) * (double)cpg_;
+        const double d = (double)o[0] - m;
+        Q += (double)o[1] + nk * d * d;
+      }
     sQ[threadIdx.x] = Q;
   }
   __syncthreads();
   if (threadIdx.x < G) {
     const int g = threadIdx.x;
-    double S = 0.0, Q = 0.0;
-    for (int part = 0; part < parts; ++part) {
-      S += sS[part * G + g];
-      Q += sQ[part * G + g];
-    }
+    double Q = 0.0;
+    for (int part = 0; part < parts; ++part) Q += sQ[part * G + g];
     const double n = (double)HW * (double)(C / G);
-    const double m = S / n;
-    double var = Q / n - m * m;
+    const double m = sMean[g];
+    double var = Q / n;
     if (var < 0.0) var = 0.0;
     const float mf = (float)m, rf = (float)(1.0 / sqrt(var + (double)eps));
     smean[g] = mf;
@@ -202,8 +254,8 @@ __global__ __launch_bounds__(256) void track_final_kernel(const float* __restric
   if (threadIdx.x < 4 && c0 + (int)threadIdx.x < C) out[c0 + threadIdx.x] = (float)(red[0][threadIdx.x] * (double)inv_count);
 }
 
-template <bool SILU>
-__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ g,
+template <bool SILU, bool GBF>
+__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __restrict__ x, const void* __restrict__ g,
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ rstd,
                                                              const float* __restrict__ gamma,
@@ -219,11 +271,11 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __rest
   const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
   const f32x4 be = *reinterpret_cast<const f32x4*>(beta + c);
   const float* xb = x + (int64_t)b * HW * C;
-  const float* gb = g + (int64_t)b * HW * C;
+  const int64_t gb4 = (int64_t)b * HW * (C / 4);
   f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
   for (int pix = p0 + l.pr; pix < p1; pix += l.PR) {
     f32x4 v = *reinterpret_cast<const f32x4*>(xb + (int64_t)pix * C + c);
-    f32x4 gv = *reinterpret_cast<const f32x4*>(gb + (int64_t)pix * C + c);
+    f32x4 gv = load4g<GBF>(g, gb4 + (int64_t)pix * (C / 4) + l.cq);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float xh = (v[e] - mu) * rs;
@@ -251,11 +303,38 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __rest
   }
 }
 
-// stage 2a: one workgroup per batch item: chunk totals per (b,c) (kept in ws[b][0][c][:]) and the group coefficients
-__global__ __launch_bounds__(256) void gn_bwd_final_kernel(float* __restrict__ ws, const float* __restrict__ rstd,
-                                                           const float* __restrict__ gamma, int HW, int C, int G,
-                                                           int nchunk, float* __restrict__ coef) {
+// stage 2b (same launch as 2a, workgroups B .. B + ceil(C/256) - 1): dgamma/dbeta = sum over batch items and chunks of the
+// stage-1 partials, chunk order inside a batch item, then batch order -- exactly the sums stage 2a forms per batch item
+// (it cannot read 2a's totals: the two roles run concurrently)
+__device__ __forceinline__ void gn_bwd_dparam_role(const float* __restrict__ ws, int blk, int B, int C, int nchunk,
+                                                   float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blk * 256 + threadIdx.x;
+  if (c >= C) return;
+  double a1 = 0.0, a2 = 0.0;
+  for (int b = 0; b < B; ++b) {
+    double b1 = 0.0, b2 = 0.0;
+    for (int k = 0; k < nchunk; ++k) {
+      const float* o = ws + (((int64_t)b * nchunk + k) * C + c) * 2;
+      b1 += (double)o[0];
+      b2 += (double)o[1];
+    }
+    a1 += (double)(float)b1;  // 2a rounds a batch item's total to fp32 before it is used: the same value here
+    a2 += (double)(float)b2;
+  }
+  dbeta[c] = (float)a1;
+  dgamma[c] = (float)a2;
+}
+
+// stage 2a: one workgroup per batch item: chunk totals per (b,c) and the group coefficients
+__global__ __launch_bounds__(256) void gn_bwd_final_kernel(const float* __restrict__ ws, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, int B, int HW, int C, int G,
+                                                           int nchunk, float* __restrict__ coef, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta) {
   __shared__ float sg1[1024], sg2[1024];
+  if ((int)blockIdx.x >= B) {  // uniform per workgroup
+    gn_bwd_dparam_role(ws, blockIdx.x - B, B, C, nchunk, dgamma, dbeta);
+    return;
+  }
   const int cpg = C / G;
   const int b = blockIdx.x;
   for (int c = threadIdx.x; c < C; c += 256) {
@@ -265,9 +344,6 @@ __global__ __launch_bounds__(256) void gn_bwd_final_kernel(float* __restrict__ w
       a1 += (double)o[0];
       a2 += (double)o[1];
     }
-    float* o0 = ws + (((int64_t)b * nchunk) * C + c) * 2;  // only this thread touches column c of batch b
-    o0[0] = (float)a1;
-    o0[1] = (float)a2;
     sg1[c] = (float)(a1 * (double)gamma[c]);
     sg2[c] = (float)(a2 * (double)gamma[c]);
   }
@@ -284,30 +360,16 @@ __global__ __launch_bounds__(256) void gn_bwd_final_kernel(float* __restrict__ w
     coef[((int64_t)b * G + g) * 2 + 1] = (float)(r * s1 / n);
   }
 }
-// stage 2b: dgamma/dbeta = sum over the batch of the per-(b,c) totals
-__global__ __launch_bounds__(256) void gn_bwd_dparam_kernel(const float* __restrict__ ws, int B, int C, int nchunk,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  double a1 = 0.0, a2 = 0.0;
-  for (int b = 0; b < B; ++b) {
-    const float* o = ws + (((int64_t)b * nchunk) * C + c) * 2;
-    a1 += (double)o[0];
-    a2 += (double)o[1];
-  }
-  dbeta[c] = (float)a1;
-  dgamma[c] = (float)a2;
-}
-
-template <bool SILU>
-__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ g,
+template <bool SILU, bool GBF>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, const void* __restrict__ g,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta,
                                                            const float* __restrict__ coef,
                                                            const float* __restrict__ add, int64_t n4, int HWQ, int Q,
-                                                           int C, int G, float* __restrict__ dx) {
+                                                           int C, int G, float* __restrict__ dx,
+                                                           unsigned short* __restrict__ dx16) {
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * 256;
   const int cpg = C / G;
@@ -318,7 +380,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
     const float mu = mean[b * G + grp], rs = rstd[b * G + grp];
     const float k0 = coef[((int64_t)b * G + grp) * 2 + 0], k1 = coef[((int64_t)b * G + grp) * 2 + 1];
     f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
-    f32x4 gv = *reinterpret_cast<const f32x4*>(g + i * 4);
+    f32x4 gv = load4g<GBF>(g, i);
     f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
     f32x4 be = *reinterpret_cast<const f32x4*>(beta + c);
     f32x4 o;
@@ -331,7 +393,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
       if (SILU) du *= silu_grad_f(xh * ga[e] + be[e]);
       o[e] += du * (rs * ga[e]) - xh * k0 - k1;
     }
-    *reinterpret_cast<f32x4*>(dx + i * 4) = o;
+    if (dx) *reinterpret_cast<f32x4*>(dx + i * 4) = o;
+    if (dx16) *reinterpret_cast<uint2*>(dx16 + i * 4) = pack4_bf16(o);
   }
 }
 
@@ -413,50 +476,45 @@ extern "C" int vae_track_final(const float* ws, int32_t rows, int32_t C, float i
   return VAE_OK;
 }
 
-extern "C" int vae_gn_bwd_partial(const float* x, const float* g, const float* mean, const float* rstd,
+extern "C" int vae_gn_bwd_partial(const float* x, const void* g, const float* mean, const float* rstd,
                                   const float* gamma, const float* beta, int32_t B, int32_t HW, int32_t C, int32_t G,
-                                  int32_t nchunk, int32_t silu, float* ws, void* stream) {
+                                  int32_t nchunk, int32_t silu, int32_t g_bf16, float* ws, void* stream) {
   if (int e = check_gn("gn_bwd_partial", B, HW, C, G, nchunk)) return e;
   VAE_CHECK(x && g && mean && rstd && gamma && beta && ws, "gn_bwd_partial: null pointer");
   VAE_CHECK(aligned16(x) && aligned16(g) && aligned16(gamma) && aligned16(beta), "gn_bwd_partial: unaligned");
-  if (silu)
-    hipLaunchKernelGGL(gn_bwd_partial_kernel<true>, dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream, x, g, mean, rstd,
-                       gamma, beta, HW, C, G, nchunk, ws);
-  else
-    hipLaunchKernelGGL(gn_bwd_partial_kernel<false>, dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream, x, g, mean, rstd,
-                       gamma, beta, HW, C, G, nchunk, ws);
+#define GNP(S, BF) hipLaunchKernelGGL((gn_bwd_partial_kernel<S, BF>), dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream, x, g, mean, rstd, gamma, beta, HW, C, G, nchunk, ws)
+  if (silu) { if (g_bf16) GNP(true, true); else GNP(true, false); }
+  else { if (g_bf16) GNP(false, true); else GNP(false, false); }
+#undef GNP
   VAE_LAUNCH_CHECK("gn_bwd_partial");
   return VAE_OK;
 }
 
-extern "C" int vae_gn_bwd_final(float* ws, const float* rstd, const float* gamma, int32_t B, int32_t HW, int32_t C,
+extern "C" int vae_gn_bwd_final(const float* ws, const float* rstd, const float* gamma, int32_t B, int32_t HW, int32_t C,
                                 int32_t G, int32_t nchunk, float* dgamma, float* dbeta, float* coef, void* stream) {
   if (int e = check_gn("gn_bwd_final", B, HW, C, G, nchunk)) return e;
   VAE_CHECK(ws && rstd && gamma && dgamma && dbeta && coef, "gn_bwd_final: null pointer");
   VAE_CHECK(C <= 1024, "gn_bwd_final: C > 1024");
-  hipLaunchKernelGGL(gn_bwd_final_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, ws, rstd, gamma, HW, C, G, nchunk, coef);
-  hipLaunchKernelGGL(gn_bwd_dparam_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, B, C, nchunk, dgamma,
-                     dbeta);
+  hipLaunchKernelGGL(gn_bwd_final_kernel, dim3(B + (C + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, rstd, gamma, B, HW, C, G,
+                     nchunk, coef, dgamma, dbeta);
   VAE_LAUNCH_CHECK("gn_bwd_final");
   return VAE_OK;
 }
 
-extern "C" int vae_gn_bwd_apply(const float* x, const float* g, const float* mean, const float* rstd,
+extern "C" int vae_gn_bwd_apply(const float* x, const void* g, const float* mean, const float* rstd,
                                 const float* gamma, const float* beta, const float* coef, const float* add, int32_t B,
-                                int32_t HW, int32_t C, int32_t G, int32_t silu, float* dx, void* stream) {
+                                int32_t HW, int32_t C, int32_t G, int32_t silu, int32_t g_bf16, float* dx, void* dx16, void* stream) {
   if (int e = check_gn("gn_bwd_apply", B, HW, C, G, 1)) return e;
-  VAE_CHECK(x && g && mean && rstd && gamma && beta && coef && dx, "gn_bwd_apply: null pointer");
-  VAE_CHECK(aligned16(x) && aligned16(g) && aligned16(dx) && aligned16(gamma) && aligned16(beta) &&
+  VAE_CHECK(x && g && mean && rstd && gamma && beta && coef && (dx || dx16), "gn_bwd_apply: null pointer");
+  VAE_CHECK(aligned16(x) && aligned16(g) && aligned16(dx) && aligned16(dx16) && aligned16(gamma) && aligned16(beta) &&
                 (add == nullptr || aligned16(add)),
             "gn_bwd_apply: unaligned");
   const int Q = C / 4;
   const int64_t n4 = (int64_t)B * HW * Q;
-  if (silu)
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, x, g, mean, rstd,
-                       gamma, beta, coef, add, n4, HW * Q, Q, C, G, dx);
-  else
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, x, g, mean, rstd,
-                       gamma, beta, coef, add, n4, HW * Q, Q, C, G, dx);
+#define GNA(S, BF) hipLaunchKernelGGL((gn_bwd_apply_kernel<S, BF>), dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, x, g, mean, rstd, gamma, beta, coef, add, n4, HW * Q, Q, C, G, dx, (unsigned short*)dx16)
+  if (silu) { if (g_bf16) GNA(true, true); else GNA(true, false); }
+  else { if (g_bf16) GNA(false, true); else GNA(false, false); }
+#undef GNA
   VAE_LAUNCH_CHECK("gn_bwd_apply");
   return VAE_OK;
 }

@@ -79,16 +79,21 @@ class DeadNeuronTracker:
                 o = arena.offset_of[id(p)]
                 offs.append((o, o + p.numel()))
             seg = torch.tensor([[b, e] for b, e in offs], dtype=torch.int64)
-            self._plan = (key, seg, torch.tensor([e - b for b, e in offs], dtype=torch.float64))
-        _, seg, numel = self._plan
-        n = seg.shape[0]
+            ch = lib.query("vae_dead_scan_chunk")  # elements per workgroup
+            c0 = np.concatenate([[0], np.cumsum([max(1, -(-(e - b) // ch)) for b, e in offs])]).astype(np.int32)
+            self._plan = (key, seg.to(dev).contiguous().view(-1), torch.tensor([e - b for b, e in offs], dtype=torch.float64),
+                          torch.from_numpy(c0).to(dev), int(c0[-1]))
+        _, seg_dev, numel, chunk0, nchunk = self._plan  # seg_dev: [n][2] = {begin, end} offsets into the arena
+        n = numel.shape[0]
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         counts = torch.zeros(n, dtype=torch.int64, device=dev)
         abssum = torch.zeros(n, dtype=torch.float64, device=dev)
-        seg_dev = seg.to(dev).contiguous().view(-1)  # [n][2] = {begin, end} offsets into the arena
+        pcnt = torch.empty(nchunk, dtype=torch.int64, device=dev)
+        psum = torch.empty(nchunk, dtype=torch.float64, device=dev)
         base = arena.flat
-        lib.call("vae_dead_scan", C.c_void_p(base.data_ptr()), C.c_void_p(seg_dev.data_ptr()), n,
-                 float(np.float32(self.threshold)), C.c_void_p(counts.data_ptr()), C.c_void_p(abssum.data_ptr()), stream)
+        lib.call("vae_dead_scan", C.c_void_p(base.data_ptr()), C.c_void_p(seg_dev.data_ptr()), C.c_void_p(chunk0.data_ptr()), n, nchunk,
+                 float(np.float32(self.threshold)), C.c_void_p(pcnt.data_ptr()), C.c_void_p(psum.data_ptr()),
+                 C.c_void_p(counts.data_ptr()), C.c_void_p(abssum.data_ptr()), stream)
         if self.dead_type == "threshold":
             c = counts.cpu().numpy().astype(np.float64)
             return [float(ci / ni * 100.0) for ci, ni in zip(c, numel.numpy())]
@@ -97,9 +102,9 @@ class DeadNeuronTracker:
         athr = np.where(degenerate, 1e-9, self.mean_percentage * mean_abs.astype(np.float64)).astype(np.float32)
         athr_dev = torch.from_numpy(athr).to(dev)
         use_fixed = 1 if self.dead_type == "both" else 0
-        lib.call("vae_dead_scan_adaptive", C.c_void_p(base.data_ptr()), C.c_void_p(seg_dev.data_ptr()), n,
-                 float(np.float32(self.threshold)), use_fixed, C.c_void_p(athr_dev.data_ptr()),
-                 C.c_void_p(counts.data_ptr()), stream)
+        lib.call("vae_dead_scan_adaptive", C.c_void_p(base.data_ptr()), C.c_void_p(seg_dev.data_ptr()), C.c_void_p(chunk0.data_ptr()), n,
+                 nchunk, float(np.float32(self.threshold)), use_fixed, C.c_void_p(athr_dev.data_ptr()),
+                 C.c_void_p(pcnt.data_ptr()), C.c_void_p(counts.data_ptr()), stream)
         c = counts.cpu().numpy().astype(np.float64)
         out = []
         for ci, ni, deg in zip(c, numel.numpy(), degenerate):

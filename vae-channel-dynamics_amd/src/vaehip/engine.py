@@ -224,16 +224,32 @@ class Engine:
         a16, self._last16 = self._last16, None
         return a16 if recording else None
 
-    def _conv_bwd(self, m, x, dy, xf, st, need_dx=True, x16=None):
+    def _conv_bwd(self, m, x, dy, xf, st, need_dx=True, x16=None, dx_to_gn=False):
+        """dy: fp32 (possibly carrying a bf16 image) or bf16; dx_to_gn: the input gradient goes to a GroupNorm backward and
+        nowhere else, so bf16 mode may store it as bf16"""
         kind = getattr(m, "kind", "c1")
+        if (need_dx and dy.dtype == torch.float32 and getattr(dy, "_b16", None) is None
+                and ops.grad_image_ok(kind, x.shape[:3] + (m.weight.shape[1],), m.weight.shape[0], m.weight.shape[1])):
+            # a gradient that arrives without its bf16 image (from an upsampler, an attention block, the loss): rounding it
+            # once here costs what the two consumers save in reads, and puts both on the kernels that take an image
+            dy._b16 = ops.pack_bf16(dy, torch.empty(dy.shape, device=dy.device, dtype=torch.bfloat16))
         ops.conv_wgrad(dy, x, kind, self._g(m.weight), self._g(m.bias), xf=xf, stats=st, x16=x16)
         if need_dx:
-            return ops.conv_dgrad(dy, m.weight, kind, (x.shape[1], x.shape[2]))
+            return ops.conv_dgrad(dy, m.weight, kind, (x.shape[1], x.shape[2]), out_bf16=dx_to_gn)
         return None
 
-    def _gn_bwd(self, norm, x, g, st, silu, add):
+    def _gn_bwd(self, norm, x, g, st, silu, add, conv_only=None, feeds_conv3=False):
+        """conv_only: the convolution that is the ONLY consumer of the result (a resnet's dL/dh -> conv1): stored as bf16
+        alone when its kernels take a bf16 gradient image.  feeds_conv3: the result continues the residual stream (fp32) and
+        is also the output gradient of a 3x3 convolution upstream: a bf16 image is attached for that consumer."""
+        want32, want16 = True, False
+        if conv_only is not None and ops.grad_image_ok(getattr(conv_only, "kind", "c1"), x.shape[:3] + (conv_only.weight.shape[1],),
+                                                      conv_only.weight.shape[0], conv_only.weight.shape[1]):
+            want32, want16 = False, True
+        elif feeds_conv3 and ops.grad_image_ok("c3", x.shape, x.shape[3], x.shape[3]):
+            want16 = True
         return ops.gn_bwd(x, g, st, norm.weight, norm.bias, silu, add, self._g(norm.weight), self._g(norm.bias),
-                          norm.num_groups)
+                          norm.num_groups, want32=want32, want16=want16)
 
     # ------------------------------------------------------------------ blocks
     def _plain_conv(self, m, x, tape, need_dx=True, owner=None):
@@ -266,7 +282,8 @@ class Engine:
         tape.append(bwd)
         return y
 
-    def _resnet(self, r, x, tape, notify=True):
+    def _resnet(self, r, x, tape, notify=True, after_conv3=False):
+        """after_conv3: what produced x is the output of a 3x3 stride-1 convolution of the same width (a resnet's conv2)"""
         self._no_hooks(r.nonlinearity, "ResnetBlock2D.nonlinearity")
         self._no_hooks(r.dropout, "ResnetBlock2D.dropout")
         self._pre(r, lambda: x)
@@ -281,11 +298,11 @@ class Engine:
         self._post(r, lambda: x, out)
         if tape is not None:
             def bwd(dout):
-                g2 = self._conv_bwd(r.conv2, h, dout, XF_AFFINE_SILU, st2, x16=h16)
-                dh = self._gn_bwd(r.norm2, h, g2, st2, True, None)
-                g1 = self._conv_bwd(r.conv1, x, dh, XF_AFFINE_SILU, st1, x16=x16)
+                g2 = self._conv_bwd(r.conv2, h, dout, XF_AFFINE_SILU, st2, x16=h16, dx_to_gn=True)
+                dh = self._gn_bwd(r.norm2, h, g2, st2, True, None, conv_only=r.conv1)  # dL/dh only feeds conv1's wgrad + dgrad
+                g1 = self._conv_bwd(r.conv1, x, dh, XF_AFFINE_SILU, st1, x16=x16, dx_to_gn=True)
                 dsc = self._conv_bwd(r.conv_shortcut, x, dout, XF_NONE, None) if r.conv_shortcut is not None else dout
-                dx = self._gn_bwd(r.norm1, x, g1, st1, True, dsc)
+                dx = self._gn_bwd(r.norm1, x, g1, st1, True, dsc, feeds_conv3=after_conv3)
                 if notify is True:
                     self._done(r)
                 elif notify is not False:
@@ -294,7 +311,7 @@ class Engine:
             tape.append(bwd)
         return out
 
-    def _attention(self, a, x, tape, notify=True):
+    def _attention(self, a, x, tape, notify=True, after_conv3=False):
         self._pre(a, lambda: x)
         B, H, W, Cc = x.shape
         T = H * W
@@ -335,7 +352,7 @@ class Engine:
                 g = self._conv_bwd(a.to_q, x, dq.view(B, H, W, Cc), XF_AFFINE, st)
                 g = ops.add(g, self._conv_bwd(a.to_k, x, dk.view(B, H, W, Cc), XF_AFFINE, st))
                 g = ops.add(g, self._conv_bwd(a.to_v, x, dv.view(B, H, W, Cc), XF_AFFINE, st))
-                dx = self._gn_bwd(a.group_norm, x, g, st, False, dout)
+                dx = self._gn_bwd(a.group_norm, x, g, st, False, dout, feeds_conv3=after_conv3)
                 if notify:
                     self._done(a)
                 return dx
@@ -347,7 +364,7 @@ class Engine:
         # registration order (attentions, resnets) differs from execution order, so the DP watermark
         # only moves once the whole mid block is final: after resnets[0]'s backward (last on the tape)
         h = self._seg(lambda t, tp: self._resnet(mb.resnets[0], t, tp, notify=mb), x, tape)
-        h = self._seg(lambda t, tp: self._attention(mb.attentions[0], t, tp, notify=False), h, tape)
+        h = self._seg(lambda t, tp: self._attention(mb.attentions[0], t, tp, notify=False, after_conv3=True), h, tape)
         h = self._seg(lambda t, tp: self._resnet(mb.resnets[1], t, tp, notify=False), h, tape)
         self._post(mb, lambda: x, h)
         return h
@@ -361,8 +378,8 @@ class Engine:
     def _updown_block(self, blk, x, tape):
         self._pre(blk, lambda: x)
         h = x
-        for r in blk.resnets:
-            h = self._seg(lambda t, tp, r=r: self._resnet(r, t, tp), h, tape)
+        for i, r in enumerate(blk.resnets):  # a resnet after the first one continues the output of the previous one's conv2
+            h = self._seg(lambda t, tp, r=r, i=i: self._resnet(r, t, tp, after_conv3=i > 0), h, tape)
         extra = getattr(blk, "downsamplers", None) or getattr(blk, "upsamplers", None)
         if extra is not None:
             h = self._seg(lambda t, tp: self._sampler(extra[0], t, tp), h, tape)
@@ -377,8 +394,8 @@ class Engine:
         x16 = self._take16(tape is not None)
         if tape is not None:
             def bwd(d):
-                g = self._conv_bwd(conv, x, d, XF_AFFINE_SILU, st, x16=x16)
-                dx = self._gn_bwd(norm, x, g, st, True, None)
+                g = self._conv_bwd(conv, x, d, XF_AFFINE_SILU, st, x16=x16, dx_to_gn=True)
+                dx = self._gn_bwd(norm, x, g, st, True, None, feeds_conv3=True)
                 self._done(conv)
                 self._done(norm)
                 return dx

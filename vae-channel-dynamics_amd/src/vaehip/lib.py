@@ -29,14 +29,14 @@ class IgemmArgs(C.Structure):
                 ("xf", C.c_int32), ("alpha", C.c_float), ("prec", C.c_int32), ("Wh", _fp), ("A16", _fp),
                 ("tapmask", C.c_int32), ("a_step", C.c_int32), ("a_oy", C.c_int32), ("a_ox", C.c_int32),
                 ("c_step", C.c_int32), ("c_oy", C.c_int32), ("c_ox", C.c_int32),
-                ("gstat", _fp), ("gstat_groups", C.c_int32)]
+                ("gstat", _fp), ("gstat_groups", C.c_int32), ("out_bf16", C.c_int32)]
 
 
 class WgradArgs(C.Structure):
     _fields_ = [("dY", _fp), ("X", _fp), ("out", _fp), ("partial", _fp), ("bias_partial", _fp), ("scale", _fp), ("shift", _fp),
                 ("g", ConvGeom), ("M", C.c_int32), ("N", C.c_int32), ("ldy", C.c_int32), ("npix", C.c_int32),
                 ("nsplit", C.c_int32), ("batch", C.c_int32), ("sYb", C.c_int64), ("sXb", C.c_int64),
-                ("sOb", C.c_int64), ("xf", C.c_int32), ("alpha", C.c_float), ("prec", C.c_int32), ("X16", _fp),
+                ("sOb", C.c_int64), ("xf", C.c_int32), ("alpha", C.c_float), ("prec", C.c_int32), ("X16", _fp), ("dY16", _fp),
                 ("tapmask", C.c_int32), ("y_step", C.c_int32), ("y_oy", C.c_int32), ("y_ox", C.c_int32)]
 
 
@@ -48,6 +48,8 @@ SIGNATURES = {
     "vae_igemm_rows": [C.POINTER(IgemmArgs), vp],
     "vae_conv_gstat_chunks": [C.POINTER(IgemmArgs)],
     "vae_conv_phase_ok": [C.POINTER(IgemmArgs)],
+    "vae_conv_out_bf16_ok": [C.POINTER(IgemmArgs)],
+    "vae_bf16_grad_image_ok": [C.POINTER(ConvGeom), i32, i32],
     "vae_upconv_phase_weights": [vp, i32, i32, vp, vp],
     "vae_wgrad_phase_ok": [C.POINTER(WgradArgs)],
     "vae_upconv_fold_wgrad": [vp, vp, i32, i32, vp, vp, vp],
@@ -57,6 +59,7 @@ SIGNATURES = {
     "vae_igemm_kernel_name": [C.POINTER(IgemmArgs), C.c_char_p, i32],
     "vae_wgrad_kernel_name": [C.POINTER(WgradArgs), C.c_char_p, i32],
     "vae_reduce_splits": [vp, i32, i64, vp, vp],
+    "vae_reduce_splits2": [vp, i32, i64, vp, vp, i32, vp, vp],
     "vae_gn_stats_partial": [vp, i32, i32, i32, i32, i32, vp, vp],
     "vae_gn_stats_final": [vp, i32, i32, i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp],
     "vae_gn_apply": [vp, vp, vp, i32, i32, i32, i32, vp, vp],
@@ -64,9 +67,9 @@ SIGNATURES = {
     "vae_bf16_act_image_ok": [C.POINTER(ConvGeom), i32, i32],
     "vae_gn_track_partial": [vp, vp, vp, i32, i32, i32, i32, vp, vp],
     "vae_track_final": [vp, i32, i32, f32, vp, vp],
-    "vae_gn_bwd_partial": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp],
+    "vae_gn_bwd_partial": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp],
     "vae_gn_bwd_final": [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp],
-    "vae_gn_bwd_apply": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp],
+    "vae_gn_bwd_apply": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp],
     "vae_attn_supported": [i32, i32],
     "vae_attn_fwd": [vp, vp, vp, i32, i32, i32, f32, i32, vp, vp, vp],
     "vae_attn_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp],
@@ -85,8 +88,9 @@ SIGNATURES = {
     "vae_preprocess_u8": [vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, i32, i32, vp, vp, vp],
     "vae_sqnorm": [vp, i64, vp, i32, vp, vp],
     "vae_adamw": [vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, f32, i32, vp],
-    "vae_dead_scan": [vp, vp, i32, f32, vp, vp, vp],
-    "vae_dead_scan_adaptive": [vp, vp, i32, f32, i32, vp, vp, vp],
+    "vae_dead_scan_chunk": [],
+    "vae_dead_scan": [vp, vp, vp, i32, i32, f32, vp, vp, vp, vp, vp],
+    "vae_dead_scan_adaptive": [vp, vp, vp, i32, i32, f32, i32, vp, vp, vp, vp],
 }
 
 

@@ -182,6 +182,28 @@ def act_image_ok(kind: str, x_shape, Co: int, Ci: int) -> bool:
     return bool(lib.query("vae_bf16_act_image_ok", C.byref(g), Co, Ci))
 
 
+# bf16 mode stores gradients that only feed bf16 kernels as bf16 images (the dgrad outputs of the halo-tile kernels and the
+# GroupNorm-backward outputs): half the bytes in the HBM-bound GroupNorm backward, and the wgrad / dgrad kernels copy them to
+# LDS as they are.  False = fp32 gradients everywhere (the round-1 behaviour).
+GRAD_IMAGES = True
+
+
+def grad_image_ok(kind: str, x_shape, Co: int, Ci: int) -> bool:
+    """bf16 mode: may the OUTPUT gradient of this layer (forward input x_shape) be handed to its dgrad and wgrad as a bf16 image?"""
+    if PRECISION != PREC_BF16 or WEIGHTS16 is None or kind != "c3" or not GRAD_IMAGES:
+        return False
+    B, H, W, Cs = x_shape
+    g = _fwd_geom(kind, B, H, W, Cs)
+    return bool(lib.query("vae_bf16_grad_image_ok", C.byref(g), int(Co), int(Ci)))
+
+
+def _grad16(dy: torch.Tensor) -> Optional[torch.Tensor]:
+    """the bf16 image of a gradient tensor: the tensor itself when it is stored as bf16, or the copy its producer attached"""
+    if dy.dtype == torch.bfloat16:
+        return dy
+    return getattr(dy, "_b16", None)
+
+
 def gn_apply_bf16(x: torch.Tensor, st: "Stats", xf: int) -> torch.Tensor:
     """bf16(XF(x)) as a [B,H,W,C] bfloat16 tensor: the activation image conv_fwd(a16=) / conv_wgrad(x16=) read."""
     B, H, W, Cc = x.shape
@@ -340,17 +362,25 @@ def conv_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], kin
     return out
 
 
-def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, kind: str, in_hw: Tuple[int, int]) -> torch.Tensor:
-    """gradient wrt the conv input (the XF'ed tensor); dy [B,Ho,Wo,Co] -> [B,H,W,Ci]."""
-    _chk_c(dy, "conv_dgrad.dy")
+def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, kind: str, in_hw: Tuple[int, int], out_bf16: bool = False) -> torch.Tensor:
+    """gradient wrt the conv input (the XF'ed tensor); dy [B,Ho,Wo,Co] -> [B,H,W,Ci].
+    dy: fp32 (optionally with a bf16 image attached, `_b16`) or a bf16 tensor; out_bf16: store the result as bf16 when the
+    kernel serving the layer can (the caller feeds it to gn_bwd only) -- otherwise fp32 as ever."""
+    dy16 = _grad16(dy)
+    dy32 = dy if dy.dtype == torch.float32 else None
+    if dy32 is not None:
+        _chk_c(dy32, "conv_dgrad.dy")
     wv = ohwi(w)
     Co, kh, kw, Ci = wv.shape
     taps = kh * kw
     B, Hy, Wy, Cy = dy.shape
     assert Cy == Co
     H, W = in_hw
+    use16 = dy16 is not None and grad_image_ok(kind, (B, H, W, Ci), Co, Ci)
+    if dy32 is None and not use16:
+        raise ValueError("conv_dgrad: a bf16-only gradient reached a layer whose kernels need fp32")
     if kind == "c3up" and PHASE_UPCONV:
-        out = _upconv_phase_dgrad(dy, wv, in_hw)
+        out = _upconv_phase_dgrad(dy32, wv, in_hw)
         if out is not None:
             return out
     if kind == "c3up":
@@ -365,17 +395,26 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, kind: str, in_hw: Tuple[int, i
     if kind == "c3s2" and H % 2 == 0 and W % 2 == 0 and (B * H * W // 4) % 128 == 0:
         mode = MODE_DGRAD_S2  # parity-class-major rows: only the taps a class meets are computed (9/4 instead of 9)
     g = ConvGeom(B, Hy, Wy, Co, Hr, Wr, taps, stride, pad, pad, mode)
-    out = torch.empty((B, Hr, Wr, Ci), device=dy.device, dtype=torch.float32)
     a = IgemmArgs()
-    a.A, a.W, a.C = _p(dy), _p(wv), _p(out)
+    src = dy16 if use16 else dy32
+    a.A, a.W = _p(dy32 if dy32 is not None else dy16), _p(wv)  # with A16 the kernel reads the image; A only gives the alignment
+    a.A16 = _p(dy16) if use16 else None
     a.g = g
     a.M, a.N, a.K, a.ldc = B * Hr * Wr, Ci, Co, Ci
     a.sn, a.sk, a.st = 1, taps * Ci, Ci
     a.batch, a.sAb, a.sWb, a.sCb = 1, 0, 0, 0
     a.xf, a.alpha, a.prec, a.Wh = XF_NONE, 1.0, PRECISION, _wh(wv)
+    o16 = False
+    if out_bf16 and PRECISION == PREC_BF16 and GRAD_IMAGES and kind == "c3":
+        a.out_bf16 = 1
+        a.C = a.A  # placeholder with the right alignment for the query
+        o16 = bool(lib.query("vae_conv_out_bf16_ok", C.byref(a)))
+        a.out_bf16 = 1 if o16 else 0
+    out = torch.empty((B, Hr, Wr, Ci), device=src.device, dtype=torch.bfloat16 if o16 else torch.float32)
+    a.C = _p(out)
     _launch_igemm(a)
     if kind == "c3up":
-        pooled = torch.empty((B, H, W, Ci), device=dy.device, dtype=torch.float32)
+        pooled = torch.empty((B, H, W, Ci), device=src.device, dtype=torch.float32)
         lib.call("vae_sumpool2x2", _p(out), B, H, W, Ci, _p(pooled), _stream())
         return pooled
     return out
@@ -429,7 +468,10 @@ def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, kind: str, wgrad_out: torch.Te
                x16: Optional[torch.Tensor] = None):
     """writes dW into `wgrad_out` (a view with the weight's OHWI memory) and db into `bgrad_out`.
     x16: bf16 image of XF(x) (as conv_fwd's a16)."""
-    _chk_c(dy, "conv_wgrad.dy")
+    dy16 = _grad16(dy)
+    dy32 = dy if dy.dtype == torch.float32 else None
+    if dy32 is not None:
+        _chk_c(dy32, "conv_wgrad.dy")
     _chk_c(x, "conv_wgrad.x")
     if x16 is not None:
         assert x16.shape == x.shape and x16.dtype == torch.bfloat16 and x16.is_contiguous()
@@ -441,11 +483,15 @@ def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, kind: str, wgrad_out: torch.Te
     g = _fwd_geom(kind, B, H, W, Cs)
     assert dy.shape == (B, g.Ho, g.Wo, Co), (dy.shape, (B, g.Ho, g.Wo, Co))
     if (kind == "c3up" and PHASE_UPCONV and PRECISION == PREC_F32 and xf == XF_NONE and x16 is None
-            and _upconv_phase_wgrad(dy, x, gv, bgrad_out)):
+            and _upconv_phase_wgrad(dy32, x, gv, bgrad_out)):
         return
     npix = B * g.Ho * g.Wo
+    use16 = dy16 is not None and grad_image_ok(kind, x.shape, Co, Ci)
+    if dy32 is None and not use16:
+        raise ValueError("conv_wgrad: a bf16-only gradient reached a layer whose kernels need fp32")
     a = WgradArgs()
-    a.dY, a.X = _p(dy), _p(x)
+    a.dY, a.X = _p(dy32), _p(x)
+    a.dY16 = _p(dy16) if use16 else None
     a.g = g
     a.M, a.N, a.ldy, a.npix, a.nsplit = Co, Ci, Co, npix, 1
     a.batch, a.sYb, a.sXb, a.sOb = 1, 0, 0, 0
@@ -472,9 +518,11 @@ def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, kind: str, wgrad_out: torch.Te
         bpart = torch.empty((ns, Co), device=x.device, dtype=torch.float32)
         a.bias_partial = _p(bpart)
     _launch_wgrad(a)
-    if partial is not None:
+    if partial is not None and bpart is not None:  # one launch for both reductions
+        lib.call("vae_reduce_splits2", _p(partial), ns, Co * taps * Ci, _p(gv), _p(bpart), Co, _p(bgrad_out), _stream())
+    elif partial is not None:
         lib.call("vae_reduce_splits", _p(partial), ns, Co * taps * Ci, _p(gv), _stream())
-    if bpart is not None:
+    elif bpart is not None:
         lib.call("vae_reduce_splits", _p(bpart), ns, Co, _p(bgrad_out), _stream())
 
 
@@ -539,23 +587,33 @@ def track_final(ws: torch.Tensor, count: int) -> torch.Tensor:
 
 
 def gn_bwd(x: torch.Tensor, g: torch.Tensor, st: Stats, gamma: torch.Tensor, beta: torch.Tensor, silu: bool,
-           add: Optional[torch.Tensor], dgamma: torch.Tensor, dbeta: torch.Tensor, G: int = GN_GROUPS) -> torch.Tensor:
+           add: Optional[torch.Tensor], dgamma: torch.Tensor, dbeta: torch.Tensor, G: int = GN_GROUPS,
+           want32: bool = True, want16: bool = False) -> torch.Tensor:
+    """g: fp32 or bf16 (a dgrad output stored as bf16).  Returns dx as fp32 (want32; with the bf16 image attached as `_b16`
+    when want16 too) or as a bf16 tensor alone (want16 only: a gradient that feeds bf16 convolution kernels and nothing else)."""
     _chk_c(x, "gn_bwd.x")
-    _chk_c(g, "gn_bwd.g")
-    assert g.shape == x.shape and (add is None or add.shape == x.shape)
+    g16 = g.dtype == torch.bfloat16
+    if not g16:
+        _chk_c(g, "gn_bwd.g")
+    assert g.is_contiguous() and g.shape == x.shape and (add is None or add.shape == x.shape) and (want32 or want16)
     B, H, W, Cc = x.shape
     HW = H * W
     nch = _gn_nchunk(B, HW, Cc)
     dev = x.device
     ws = torch.empty((B, nch, Cc, 2), device=dev, dtype=torch.float32)
     coef = torch.empty((B, G, 2), device=dev, dtype=torch.float32)
-    dx = torch.empty_like(x)
+    dx = torch.empty_like(x) if want32 else None
+    dx16 = torch.empty(x.shape, device=dev, dtype=torch.bfloat16) if want16 else None
     s = _stream()
     lib.call("vae_gn_bwd_partial", _p(x), _p(g), _p(st.mean), _p(st.rstd), _p(gamma), _p(beta), B, HW, Cc, G, nch,
-             int(silu), _p(ws), s)
+             int(silu), int(g16), _p(ws), s)
     lib.call("vae_gn_bwd_final", _p(ws), _p(st.rstd), _p(gamma), B, HW, Cc, G, nch, _p(dgamma), _p(dbeta), _p(coef), s)
     lib.call("vae_gn_bwd_apply", _p(x), _p(g), _p(st.mean), _p(st.rstd), _p(gamma), _p(beta), _p(coef), _p(add), B, HW,
-             Cc, G, int(silu), _p(dx), s)
+             Cc, G, int(silu), int(g16), _p(dx), _p(dx16), s)
+    if dx is None:
+        return dx16
+    if dx16 is not None:
+        dx._b16 = dx16
     return dx
 
 
