@@ -498,7 +498,7 @@ def test_bf16_activation_image(cuda, bf16_mode, packed_weights, B, C, H, W, Co):
     finally:
         ops.PROFILER = None
     names = [r[0] for r in prof.records]
-    assert names[0] == "conv3_wide_bf16_kernel<false>" or (names[0].startswith("conv3_tile_bf16_kernel") and names[0].endswith(",true>")), names
+    assert names[0] == "conv3_wide_bf16_kernel<false,3>" or (names[0].startswith("conv3_tile_bf16_kernel") and names[0].endswith(",true>")), names
     assert names[1].startswith("wgrad3_tile_bf16_kernel") and ",true," in names[1], names  # <UP, XF, X16 = true, Y16>
     assert _rel(_nchw(y), F.conv2d(img, _r16(w), None, 1, 1)) < 2e-5
     wr = w.clone().requires_grad_(True)
@@ -582,12 +582,14 @@ def test_upconv_phase_decomposition(cuda):
     assert _rel(gb.cpu(), dy.sum(dim=(0, 2, 3))) < 3e-5
 
 
-def test_bf16_upconv_phase_decomposition(cuda, bf16_mode, packed_weights):
+# (2,4,32,...): the 128-pixel halo-tile kernel with a tap mask; (7,32,64,128,256) and (3,64,64,256,256): >= 192 tiles of 8x32 pixels
+# on the low-resolution grid -- the wide-tile kernel's 2x2 tap blocks on a bf16 image of x / of dy (strided views)
+@pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 4, 32, 128, 128), (7, 32, 64, 128, 256), (3, 64, 64, 256, 256)])
+def test_bf16_upconv_phase_decomposition(cuda, bf16_mode, packed_weights, B, H, W, Ci, Co):
     """bf16 mode: the upsampler's forward and dgrad as four phase convolutions; the effective kernels (sums of fp32 taps) are
     rounded to bf16 once, so the reference rounds the SUMS, not the taps."""
     from vaehip import ops
     gen = torch.Generator().manual_seed(78)
-    B, H, W, Ci, Co = 2, 4, 32, 128, 128
     x = torch.randn(B, Ci, H, W, generator=gen)
     w = torch.randn(Co, Ci, 3, 3, generator=gen) / math.sqrt(9 * Ci)
     wd = packed_weights(_to_dev_ohwi(w))
@@ -599,7 +601,12 @@ def test_bf16_upconv_phase_decomposition(cuda, bf16_mode, packed_weights):
         dx = ops.conv_dgrad(_nhwc(dy), wd, "c3up", (H, W))
     finally:
         ops.PROFILER = None
-    assert len(prof.records) == 8 and all(r[0].startswith("conv3_tile_bf16_kernel") for r in prof.records), [r[0] for r in prof.records]
+    names = [r[0] for r in prof.records]
+    wide_f = B * (H // 8) * (W // 32) * ((Co + 127) // 128) >= 192 and H % 8 == 0
+    wide_d = B * (H // 8) * (W // 32) * ((Ci + 127) // 128) >= 192 and H % 8 == 0
+    assert len(names) == 8, names
+    assert all(n == "conv3_wide_bf16_kernel<false,2>" if wide_f else n.startswith("conv3_tile_bf16_kernel") for n in names[:4]), names
+    assert all(n == "conv3_wide_bf16_kernel<true,2>" if wide_d else n.startswith("conv3_tile_bf16_kernel") for n in names[4:]), names
     y_ref = torch.zeros(B, Co, 2 * H, 2 * W)
     xr = _r16(x).requires_grad_(True)
     for pa in (0, 1):
@@ -716,14 +723,16 @@ def test_bf16_wide_tile_kernel(cuda, bf16_mode, packed_weights, B, H, W, Ci, Co)
         ops.PROFILER = None
     names = [r[0] for r in prof.records]
     # the dgrad's channel tiles are over Ci: it needs its own >= 192 tiles to run on the wide kernel
-    dg = "conv3_wide_bf16_kernel<true>" if B * (H // 8) * (W // 32) * ((Ci + 127) // 128) >= 192 else "conv3_tile_bf16_kernel<true,false,0,true>"
-    assert names == ["conv3_wide_bf16_kernel<false>", dg, dg], names
+    dg = "conv3_wide_bf16_kernel<true,3>" if B * (H // 8) * (W // 32) * ((Ci + 127) // 128) >= 192 else "conv3_tile_bf16_kernel<true,false,0,true>"
+    # a residual input on a 128-channel contraction stays on the 128-pixel kernel (its second workgroup per CU hides the epilogue)
+    fw = "conv3_wide_bf16_kernel<false,3>" if Ci > 128 else "conv3_tile_bf16_kernel<false,false,0,true>"
+    assert names == [fw, dg, dg], names
     act = a16.float().permute(0, 3, 1, 2).cpu()            # the image the kernel read: exact bf16 values
     y_ref = F.conv2d(act, _r16(w), bias, 1, 1) + res
     assert _rel(_nchw(y), y_ref) < 2e-5
     # GroupNorm statistics of the output from the epilogue == statistics of the tensor it wrote
     g2, b2 = torch.ones(Co, device="cuda"), torch.zeros(Co, device="cuda")
-    assert hasattr(y, "_gstat") and y._gstat[2] == (H // 8) * (W // 32)
+    assert hasattr(y, "_gstat") and y._gstat[2] == ((H // 8) * (W // 32) if Ci > 128 else (H // 4) * (W // 32))
     st_f = ops.gn_stats(y, g2, b2)
     st_p = ops.gn_stats(y.clone(), g2, b2)
     assert _rel(st_f.mean, st_p.mean) < 1e-5 and _rel(st_f.rstd, st_p.rstd) < 1e-5
@@ -731,6 +740,16 @@ def test_bf16_wide_tile_kernel(cuda, bf16_mode, packed_weights, B, H, W, Ci, Co)
     (gx,) = torch.autograd.grad(F.conv2d(xr, _r16(w), None, 1, 1), xr, dy16.float().permute(0, 3, 1, 2).cpu())
     assert dx.dtype == torch.float32 and _rel(_nchw(dx), gx) < 2e-5
     assert dx16.dtype == torch.bfloat16 and torch.equal(dx16, dx.bfloat16())
+    # without a residual input every channel count runs on the wide kernel (conv1 of a resnet)
+    prof = ops.PROFILER = ops.LaunchProfiler()
+    try:
+        y0 = ops.conv_fwd(xd, wd, bias.cuda(), "c3", xf=ops.XF_AFFINE_SILU, stats=st, a16=a16, gstat_groups=32)
+    finally:
+        ops.PROFILER = None
+    assert [r[0] for r in prof.records] == ["conv3_wide_bf16_kernel<false,3>"] and y0._gstat[2] == (H // 8) * (W // 32)
+    assert _rel(_nchw(y0), y_ref - res) < 2e-5
+    st_f, st_p = ops.gn_stats(y0, g2, b2), ops.gn_stats(y0.clone(), g2, b2)
+    assert _rel(st_f.mean, st_p.mean) < 1e-5 and _rel(st_f.rstd, st_p.rstd) < 1e-5
     # the 128-pixel kernel computes the same sums in another order
     os.environ["VAEHIP_NO_WIDE"] = "1"
     try:

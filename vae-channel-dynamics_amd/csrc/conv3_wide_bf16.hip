@@ -21,6 +21,10 @@
 //     first fragments of the next stage are read BEFORE the barrier and no LDS round trip is exposed behind it;
 //   * persistent workgroups, one software pipeline across channel chunks AND tiles (the first two weight stages and the
 //     first halo of the next tile are staged during the last chunk of the current one).
+// KS = 2 serves the phase convolutions of an upsampler (vaehip.h, tapmask / a_step / c_step): a 2x2 block {kh0, kh0+1} x
+// {kw0, kw0+1} of the 3x3 window on the low-resolution grid -- 2 stages per chunk, 2 kernel rows per stage (16 of the 36
+// tap-MACs per low-resolution pixel are computed, none masked), operand pixel (y,x) at (y*a_step+a_oy, x*a_step+a_ox) of the
+// image, output pixel at (y*c_step+c_oy, x*c_step+c_ox).
 #include "bf16_frag.h"
 #include <algorithm>
 #include <type_traits>
@@ -37,14 +41,17 @@ constexpr int SB1 = BN * LDBK;     // one tap (5120 bf16); BN * LDBK == BK * LDB
 static_assert(BN * LDBK == BK * LDBN, "forward and dgrad weight tiles have the same LDS size");
 constexpr int SB = 3 * SB1;        // one stage: the 3 taps of a kernel column (30720 B)
 constexpr int LDS_BYTES = (2 * SH + 3 * SB) * 2;  // 146560 B
-constexpr int NW = 3 * BN * BK / 8 / NT;          // 6 x 16 B of weights per thread and stage
 constexpr int HQ = HP * (BK / 8);                 // 1360 x 16 B halo slots
 constexpr int HI = (HQ + NT - 1) / NT;            // 6 per thread
 
 struct Tile { int b, y0, x0, n0, lin; };
 
-template <bool DG>
-__global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p, int tiles_x, int tiles_y, int ntiles) {
+template <bool DG, int KS>
+__global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p, int tiles_x, int tiles_y, int ntiles, int kh0, int kw0) {
+  constexpr int NW = KS * BN * BK / 8 / NT;  // 16-byte weight pieces per thread and stage (6 / 4)
+  constexpr int NPK = 2 * KS;                // pieces (of 4 MFMAs) per k-group: KS kernel rows x 2 output-row pairs
+  constexpr int NA = 3 + KS, NB = 2 * KS;    // halo-row / weight fragments per k-group
+  static_assert(KS == 2 || KS == 3, "3x3 kernels or their 2x2 phase blocks");
   extern __shared__ __attribute__((aligned(16))) u16 smem[];
   u16* const sHalo = smem;            // [2][SH]
   u16* const sW = smem + 2 * SH;      // [3][SB]
@@ -57,7 +64,8 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
   const vae_conv_geom g = p.g;
   const int tilesN = (p.N + BN - 1) / BN;
   const int nch = (p.K + BK - 1) / BK;
-  const size_t img_bytes = (size_t)g.Hs * g.Ws * g.Cs * 2u;
+  const int as = (KS == 2 && p.a_step > 1) ? p.a_step : 1, cs = (KS == 2 && p.c_step > 1) ? p.c_step : 1;
+  const size_t img_bytes = (size_t)(g.Hs * as) * (g.Ws * as) * g.Cs * 2u;
   const auto rsW = VAE_BUF_RSRC(p.Wh, (size_t)(DG ? p.K * p.sk : p.N * p.sn) * 2u);
 
   const int G = gridDim.x;
@@ -85,12 +93,12 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
   // ---------------- staging: global -> registers -> LDS, one piece (16 B per thread) at a time ----------------
   // weight stream: the position of the NEXT stage to request (tile, chunk, kernel column)
   uint4 rw[NW], rh[HI];
-  int w_t = first, w_c = 0, w_kw = 0, w_n0 = 0;
+  int w_t = first, w_c = 0, w_kw = 0, w_n0 = 0;  // w_kw: column index inside the tap block
   bool w_ok = first < ntiles;
   if (w_ok) w_n0 = decode(first).n0;
   auto w_load_piece = [&](int i) {  // piece i of the stage at the stream position
     const int kh = i >> 1, rem = tid + NT * (i & 1);
-    const int tap = kh * 3 + w_kw, c0 = w_c * BK;
+    const int tap = (kh0 + kh) * 3 + kw0 + w_kw, c0 = w_c * BK;
     unsigned off;
     if (!DG) {
       const int n = w_n0 + (rem >> 2), c = c0 + (rem & 3) * 8;
@@ -102,7 +110,7 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
     rw[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsW, off, 0, 0));
   };
   auto w_advance = [&]() {
-    if (++w_kw == 3) {
+    if (++w_kw == KS) {
       w_kw = 0;
       if (++w_c == nch) {
         w_c = 0;
@@ -128,8 +136,10 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
     const int hy = h_id.y0 - 1 + ir, hx = h_id.x0 - 1 + jc;
     const int c = h_c * BK + k8 * 8;
     const bool ok = h_ok && (q < HQ) && ((unsigned)hy < (unsigned)g.Hs) && ((unsigned)hx < (unsigned)g.Ws) && (c < p.K);
-    const auto rsA = VAE_BUF_RSRC(reinterpret_cast<const u16*>(p.A16) + (int64_t)h_id.b * g.Hs * g.Ws * g.Cs, img_bytes);
-    rh[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? (unsigned)(((hy * g.Ws + hx) * g.Cs + c) * 2) : BUF_OOB, 0, 0));
+    const auto rsA = VAE_BUF_RSRC(reinterpret_cast<const u16*>(p.A16) + (int64_t)h_id.b * (g.Hs * as) * (g.Ws * as) * g.Cs, img_bytes);
+    const unsigned off = (KS == 2) ? (unsigned)((((hy * as + p.a_oy) * (g.Ws * as) + hx * as + p.a_ox) * g.Cs + c) * 2)
+                                   : (unsigned)(((hy * g.Ws + hx) * g.Cs + c) * 2);
+    rh[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? off : BUF_OOB, 0, 0));
   };
   auto h_advance = [&]() {
     if (++h_c == nch) {
@@ -146,11 +156,16 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
 
   // ---------------- fragments ----------------
   // this lane's element offsets into a halo buffer and a weight stage (the rest are compile-time constants)
-  const int aoff = ((4 * wm) * HW_ + lr) * LDH + lh * 8;
+  // A slot j (0..NA-1) is halo row 4wm + j + roff: output row r meets kernel row kh0 + khi at halo row r + kh0 + khi
+  // (forward, slot r + khi) or r + 2 - kh0 - khi (dgrad, slot r + KS-1-khi); the column shift of block column kwi is
+  // dxb + kwi (forward) or dxb - kwi (dgrad)
+  const int roff = DG ? 3 - KS - kh0 : kh0;
+  const int dxb = DG ? 2 - kw0 : kw0;
+  const int aoff = ((4 * wm + roff) * HW_ + lr + dxb) * LDH + lh * 8;
   const int boff = DG ? (lh * 8 + trq) * LDB + wn * 64 + trh * 16 + trp * 4 : (wn * 64 + lr) * LDB + lh * 8;
-  bf16x8 fa[2][6], fb[2][6];  // two sets: the k-group being multiplied and the one being fetched
-  // fragment j (0..5) of A: halo row 4wm + j, column shift dx; of B: kernel row j >> 1, channel block j & 1
-  auto fetch_a = [&](bf16x8* set, int j, const u16* sH, int dx, int kg) { set[j] = frag_direct(sH + aoff + (j * HW_ + dx) * LDH + kg * 16); };
+  bf16x8 fa[2][NA], fb[2][NB];  // two sets: the k-group being multiplied and the one being fetched
+  // fragment j of A: slot j at block column kwi; of B: kernel row j >> 1 of the block, channel block j & 1
+  auto fetch_a = [&](bf16x8* set, int j, const u16* sH, int kwi, int kg) { set[j] = frag_direct(sH + aoff + (j * HW_ + (DG ? -kwi : kwi)) * LDH + kg * 16); };
   auto fetch_b = [&](bf16x8* set, int j, const u16* sB, int kg) {
     const int kh = j >> 1, ni = j & 1;
     if (!DG) set[j] = frag_direct(sB + boff + kh * SB1 + ni * 32 * LDB + kg * 16);
@@ -162,7 +177,8 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
   Tile cur = decode(t);
   int hpar = 0;  // halo buffer of the chunk being multiplied
 
-  // prologue: stages (0,0) and (0,1) and the first halo into LDS, stage (0,2) into registers
+  // prologue: the first two stages and the first halo into LDS, the third stage into registers
+  u16* ringB[3] = {sW, sW + SB, sW + 2 * SB};  // [0] the stage being multiplied, [1] the next one, [2] the one being written
 #pragma unroll
   for (int i = 0; i < NW; ++i) w_load_piece(i);
   w_advance();
@@ -170,97 +186,115 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
   for (int i = 0; i < HI; ++i) h_load_piece(i);
   h_advance();
 #pragma unroll
-  for (int i = 0; i < NW; ++i) w_store_piece(i, sW);
+  for (int i = 0; i < NW; ++i) w_store_piece(i, ringB[0]);
 #pragma unroll
   for (int i = 0; i < NW; ++i) w_load_piece(i);
   w_advance();
 #pragma unroll
   for (int i = 0; i < HI; ++i) h_store_piece(i, sHalo);
 #pragma unroll
-  for (int i = 0; i < NW; ++i) w_store_piece(i, sW + SB);
+  for (int i = 0; i < NW; ++i) w_store_piece(i, ringB[1]);
 #pragma unroll
   for (int i = 0; i < NW; ++i) w_load_piece(i);
   w_advance();
   __syncthreads();
 #pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    fetch_a(fa[0], j, sHalo, DG ? 2 : 0, 0);
-    fetch_b(fb[0], j, sW, 0);
-  }
+  for (int j = 0; j < NA; ++j) fetch_a(fa[0], j, sHalo, 0, 0);
+#pragma unroll
+  for (int j = 0; j < NB; ++j) fetch_b(fb[0], j, ringB[0], 0);
 
-  // One stage = kernel column KW of the current chunk: 2 k-groups x 6 pieces; a piece = 4 MFMAs (kernel row q >> 1, output
-  // rows 2(q&1), 2(q&1)+1, both channel blocks) followed by its share of the other work of the stage:
-  //   every piece      fragment j = q of A and of B for the next k-group (k-group 1: of the NEXT stage)
-  //   pieces 0..5      store piece q of weight stage +2 (requested a stage ago) into the ring slot that stage -1 used
-  //   pieces 6..11     request piece q of weight stage +3
-  //   KW == 0          pieces 0..5 request the next chunk's halo;  KW == 1  pieces 6..11 store it into the other buffer
+  // One stage = block column KWI of the current chunk: 2 k-groups x NPK pieces; a piece = 4 MFMAs (kernel row q >> 1 of the
+  // block, output rows 2(q&1), 2(q&1)+1, both channel blocks) followed by its share of the other work of the stage
+  // (piece index pi = kg * NPK + q of 2 NPK):
+  //   every piece        fragment q of A (the last piece also the remaining slots) and of B for the next k-group
+  //                      (k-group 1: of the NEXT stage)
+  //   pi < NW            store piece pi of weight stage +2 (requested a stage ago) into the ring slot that stage -1 used
+  //   pi >= 2 NPK - NW   request a piece of weight stage +3
+  //   KWI == 0           the first HI pieces request the next chunk's halo;  KWI == 1  the last HI pieces store it
   auto stage = [&](auto kw_c) {
-    constexpr int KW = decltype(kw_c)::value;
-    constexpr int KWN = (KW + 1) % 3;
+    constexpr int KWI = decltype(kw_c)::value;
+    constexpr int KWN = (KWI + 1) % KS;
     const u16* sH = sHalo + hpar * SH;
-    const u16* sHn = (KW == 2) ? sHalo + (hpar ^ 1) * SH : sH;  // the next stage's halo buffer
-    const u16* sB = sW + KW * SB;
-    const u16* sBn = sW + KWN * SB;
-    u16* sBw = sW + ((KW + 2) % 3) * SB;
+    const u16* sHn = (KWI == KS - 1) ? sHalo + (hpar ^ 1) * SH : sH;  // the next stage's halo buffer
+    const u16* sB = ringB[0];
+    const u16* sBn = ringB[1];
+    u16* sBw = ringB[2];
     u16* sHw = sHalo + (hpar ^ 1) * SH;
-    constexpr int dxn = DG ? 2 - KWN : KWN;
 #pragma unroll
     for (int kg = 0; kg < 2; ++kg) {
 #pragma unroll
-      for (int q = 0; q < 6; ++q) {
-        const int kh = q >> 1, r0 = 2 * (q & 1);
-        const int dy = DG ? 2 - kh : kh;
+      for (int q = 0; q < NPK; ++q) {
+        const int khi = q >> 1, r0 = 2 * (q & 1);
+        const int pi = kg * NPK + q;
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni)
-            acc[r0 + rr][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kg][r0 + rr + dy], fb[kg][kh * 2 + ni], acc[r0 + rr][ni], 0, 0, 0);
+            acc[r0 + rr][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kg][r0 + rr + (DG ? KS - 1 - khi : khi)], fb[kg][khi * 2 + ni],
+                                                                      acc[r0 + rr][ni], 0, 0, 0);
         if (kg == 0) {
-          fetch_a(fa[1], q, sH, DG ? 2 - KW : KW, 1);
+          fetch_a(fa[1], q, sH, KWI, 1);
+          if (q == NPK - 1)
+#pragma unroll
+            for (int j = NPK; j < NA; ++j) fetch_a(fa[1], j, sH, KWI, 1);
           fetch_b(fb[1], q, sB, 1);
-          w_store_piece(q, sBw);
-          if (KW == 0) h_load_piece(q);
         } else {
-          fetch_a(fa[0], q, sHn, dxn, 0);
+          // (KS == 2: the next chunk's halo is being STORED during this very stage when it is the chunk's last one -- a
+          // 2-stage chunk has no stage between the store and the first read -- so those fragments wait for the barrier)
+          if (!(KS == 2 && KWI == KS - 1)) {
+            fetch_a(fa[0], q, sHn, KWN, 0);
+            if (q == NPK - 1)
+#pragma unroll
+              for (int j = NPK; j < NA; ++j) fetch_a(fa[0], j, sHn, KWN, 0);
+          }
           fetch_b(fb[0], q, sBn, 0);
-          w_load_piece(q);
-          if (KW == 1) h_store_piece(q, sHw);
         }
+        if (pi < NW) w_store_piece(pi, sBw);
+        if (pi >= 2 * NPK - NW) w_load_piece(pi - (2 * NPK - NW));
+        if (KWI == 0 && pi < HI) h_load_piece(pi);
+        if (KWI == 1 && pi >= 2 * NPK - HI) h_store_piece(pi - (2 * NPK - HI), sHw);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
     w_advance();
-    if (KW == 0) h_advance();
+    if (KWI == 0) h_advance();
+    u16* t0 = ringB[0];  // rotate the ring
+    ringB[0] = ringB[1];
+    ringB[1] = ringB[2];
+    ringB[2] = t0;
     __syncthreads();
+    if (KS == 2 && KWI == KS - 1) {
+#pragma unroll
+      for (int j = 0; j < NA; ++j) fetch_a(fa[0], j, sHn, KWN, 0);
+    }
   };
-  constexpr std::integral_constant<int, 0> kw0{};
-  constexpr std::integral_constant<int, 1> kw1{};
-  constexpr std::integral_constant<int, 2> kw2{};
+  constexpr std::integral_constant<int, 0> kw0_c{};
+  constexpr std::integral_constant<int, 1> kw1_c{};
+  constexpr std::integral_constant<int, 2> kw2_c{};
 
   while (true) {
     for (int c = 0; c < nch; ++c) {
-      stage(kw0);
-      stage(kw1);
-      stage(kw2);
+      stage(kw0_c);
+      stage(kw1_c);
+      if constexpr (KS == 3) stage(kw2_c);
       hpar ^= 1;
     }
 
     // ---------------- epilogue ----------------
     float* scratch = reinterpret_cast<float*>(sHalo + (hpar ^ 1) * SH);  // the halo buffer of the chunk just finished
-    const size_t obytes = (size_t)g.Ho * g.Wo * p.ldc * 4u;
-    const auto rsC = VAE_BUF_RSRC(p.C + (int64_t)cur.b * g.Ho * g.Wo * p.ldc, obytes);
+    const size_t obytes = (size_t)(g.Ho * cs) * (g.Wo * cs) * p.ldc * 4u;
+    const auto rsC = VAE_BUF_RSRC(p.C + (int64_t)cur.b * (g.Ho * cs) * (g.Wo * cs) * p.ldc, obytes);
     const auto rsC16 = VAE_BUF_RSRC(reinterpret_cast<u16*>(p.C) + (int64_t)cur.b * g.Ho * g.Wo * p.ldc, obytes / 2);
-    const auto rsR = VAE_BUF_RSRC((p.res ? p.res : p.C) + (int64_t)cur.b * g.Ho * g.Wo * p.ldc, obytes);
+    const auto rsR = VAE_BUF_RSRC((p.res ? p.res : p.C) + (int64_t)cur.b * (g.Ho * cs) * (g.Wo * cs) * p.ldc, obytes);
     float gs1[4][2], gs2[4][2], gpv[4][2];  // statistics as shifted sums around the lane's first value
+    if (p.out_bf16) {  // uniform: adjacent lanes (adjacent channels) swap every other register: 4-byte stores
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int oy = cur.y0 + 4 * wm + r;
+      for (int r = 0; r < 4; ++r) {
+        const int oy = cur.y0 + 4 * wm + r;
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        gs1[r][ni] = gs2[r][ni] = gpv[r][ni] = 0.f;
-        const int col = cur.n0 + wn * 64 + ni * 32 + lr;
-        const bool colok = col < p.N && oy < g.Ho;
-        if (p.out_bf16) {  // uniform: adjacent lanes (adjacent channels) swap every other register: 4-byte stores
+        for (int ni = 0; ni < 2; ++ni) {
+          const int col = cur.n0 + wn * 64 + ni * 32 + lr;
+          const bool colok = col < p.N && oy < g.Ho;
           const bool odd = lr & 1;
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
@@ -277,30 +311,49 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
             acc[r][ni][2 * j] = 0.f;
             acc[r][ni][2 * j + 1] = 0.f;
           }
-          continue;
         }
-        const float bv = (p.bias && colok) ? p.bias[col] : 0.f;
-        unsigned off[16];
-        float rv[16];
+      }
+    } else {
+      // fp32 output (+ bias, + residual).  The residual is HBM-cold: its loads are issued for HALF of the wave's tile (two
+      // rows x two channel blocks, 64 registers) before any of them is consumed -- with one wave per SIMD nothing else hides
+      // that latency; issued per 16-element block they cost 8 round trips per tile (46 % of the 128-channel layers' time)
+      auto offset = [&](int r, int ni, int e) -> unsigned {
+        const int oy = cur.y0 + 4 * wm + r, col = cur.n0 + wn * 64 + ni * 32 + lr;
+        const int ox = cur.x0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (KS == 2)
+          return (col < p.N && oy < g.Ho && ox < g.Wo) ? (unsigned)((((oy * cs + p.c_oy) * (g.Wo * cs) + ox * cs + p.c_ox) * p.ldc + col) * 4) : BUF_OOB;
+        return (col < p.N && oy < g.Ho && ox < g.Wo) ? (unsigned)(((oy * g.Wo + ox) * p.ldc + col) * 4) : BUF_OOB;
+      };
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int ox = cur.x0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-          off[e] = (colok && ox < g.Wo) ? (unsigned)(((oy * g.Wo + ox) * p.ldc + col) * 4) : BUF_OOB;
-          rv[e] = 0.f;
-        }
+      for (int hf = 0; hf < 2; ++hf) {
+        float rv[4][16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) rv[q][e] = 0.f;
         if (p.res) {  // uniform
 #pragma unroll
-          for (int e = 0; e < 16; ++e) rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, off[e], 0, 0));
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+              rv[q][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, offset(2 * hf + (q >> 1), q & 1, e), 0, 0));
         }
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const float v = acc[r][ni][e] + bv + rv[e];
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, off[e], 0, 0);
-          if (e == 0) gpv[r][ni] = v;
-          const float dv = v - gpv[r][ni];  // (the statistics epilogue only runs on full tiles)
-          gs1[r][ni] += dv;
-          gs2[r][ni] += dv * dv;
-          acc[r][ni][e] = 0.f;
+        for (int q = 0; q < 4; ++q) {
+          const int r = 2 * hf + (q >> 1), ni = q & 1;
+          const int col = cur.n0 + wn * 64 + ni * 32 + lr;
+          const float bv = (p.bias && col < p.N) ? p.bias[col] : 0.f;
+          gs1[r][ni] = gs2[r][ni] = gpv[r][ni] = 0.f;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const float v = acc[r][ni][e] + bv + rv[q][e];
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, offset(r, ni, e), 0, 0);
+            if (e == 0) gpv[r][ni] = v;
+            const float dv = v - gpv[r][ni];  // (the statistics epilogue only runs on full tiles)
+            gs1[r][ni] += dv;
+            gs2[r][ni] += dv * dv;
+            acc[r][ni][e] = 0.f;
+          }
         }
       }
     }
@@ -340,47 +393,85 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
 
 }  // namespace
 
-// both operands as bf16 images, forward or dgrad of a plain (no sub-sampled view / tap subset) 3x3 stride-1 layer whose
-// spatial size the 8 x 32 tile divides, with enough tiles to give every CU one
+// a tap mask that is a 2x2 block {kh0, kh0+1} x {kw0, kw0+1} of the 3x3 window (the phase convolutions of an upsampler)
+static bool phase_block(int tapmask, int* kh0, int* kw0) {
+  for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 2; ++b) {
+      int m = 0;
+      for (int kh = a; kh < a + 2; ++kh)
+        for (int kw = b; kw < b + 2; ++kw) m |= 1 << (kh * 3 + kw);
+      if (m == tapmask) {
+        *kh0 = a;
+        *kw0 = b;
+        return true;
+      }
+    }
+  return false;
+}
+
+// both operands as bf16 images, forward or dgrad of a 3x3 stride-1 layer -- plain, or one phase convolution of an upsampler
+// (2x2 tap block, sub-sampled operand / output view) -- whose spatial size the 8 x 32 tile divides, with enough tiles to
+// give every CU one
 bool conv3_wide_bf16_eligible(const vae_igemm_args& a) {
   const vae_conv_geom& g = a.g;
   if (a.prec != VAE_PREC_BF16 || a.A16 == nullptr || a.Wh == nullptr || a.xf != VAE_XF_NONE) return false;
   if (a.batch != 1 || g.taps != 9 || g.stride != 1 || g.pad_t != 1 || g.pad_l != 1 || a.alpha != 1.0f) return false;
-  if (a.tapmask != 0 || a.a_step > 1 || a.c_step > 1 || a.track != nullptr) return false;
+  if (a.track != nullptr) return false;
+  // a residual input on a 128-channel contraction: the tile's main loop (12 stages, ~9 us) is shorter than what one CU needs
+  // to pull the 128 KB residual tile and push the 128 KB output (~10 us at a CU's ~26 GB/s), and with one workgroup per CU
+  // nothing overlaps the two -- the 128-pixel kernel's second workgroup does (measured 0.505 vs 0.588 ms at 128->128 @256^2)
+  if (a.res != nullptr && a.K <= 128 && !a.out_bf16 && a.tapmask == 0) return false;
+  const bool phase = a.tapmask != 0 || a.a_step > 1 || a.c_step > 1;
+  if (phase) {
+    int kh0, kw0;
+    if (!phase_block(a.tapmask, &kh0, &kw0) || a.out_bf16 || a.gstat) return false;
+    if ((a.a_step > 1 && a.a_step != 2) || (a.c_step > 1 && a.c_step != 2)) return false;
+  }
+  const size_t as = a.a_step > 1 ? a.a_step : 1, cs = a.c_step > 1 ? a.c_step : 1;
   if (!(g.mode == VAE_MODE_FWD || g.mode == VAE_MODE_DGRAD) || g.Ho != g.Hs || g.Wo != g.Ws) return false;
   if (g.Wo % TW != 0 || g.Ho % TH != 0 || a.K % 8 != 0 || a.N % 8 != 0 || a.N <= 32 || g.Cs % 8 != 0 || a.st % 8 != 0) return false;
   if (g.mode == VAE_MODE_FWD && !(a.sk == 1 && a.sn % 8 == 0)) return false;
   if (g.mode == VAE_MODE_DGRAD && !(a.sn == 1 && a.sk % 8 == 0)) return false;
   if (a.out_bf16 && (a.bias || a.res || a.track || a.gstat || a.ldc % 2 != 0)) return false;
   if (!aligned16(a.A16) || !aligned16(a.Wh)) return false;
-  if ((size_t)g.Hs * g.Ws * g.Cs * 4u >= BUF_MAX || (size_t)g.Ho * g.Wo * a.ldc * 4u >= BUF_MAX) return false;
+  if ((size_t)g.Hs * g.Ws * g.Cs * 4u * as * as >= BUF_MAX || (size_t)g.Ho * g.Wo * a.ldc * 4u * cs * cs >= BUF_MAX) return false;
   if ((size_t)std::max((int64_t)a.K * a.sk, (int64_t)a.N * a.sn) * 2u >= BUF_MAX) return false;
   const int64_t nt = (int64_t)((a.N + BN - 1) / BN) * (g.Wo / TW) * (g.Ho / TH) * g.B;
   return nt >= 192 && nt <= 0x7fffffffLL;
 }
 int conv3_wide_bf16_gstat_chunks(const vae_igemm_args& a) {
   const vae_conv_geom& g = a.g;
-  if (a.gstat_groups <= 0 || a.N % BN != 0 || a.N % a.gstat_groups != 0 || g.mode == VAE_MODE_DGRAD) return 0;
+  if (a.gstat_groups <= 0 || a.N % BN != 0 || a.N % a.gstat_groups != 0 || g.mode == VAE_MODE_DGRAD || a.c_step > 1 || a.tapmask != 0) return 0;
   const int cpg = a.N / a.gstat_groups;
   if (cpg != 4 && cpg != 8 && cpg != 16) return 0;
   return (g.Wo / TW) * (g.Ho / TH);
 }
+
+template <bool DG, int KS>
+static int launch_wide(const vae_igemm_args& a, int tx, int ty, int64_t nt, int kh0, int kw0, hipStream_t st) {
+  static bool attr_set = false;
+  auto kern = conv3_wide_bf16_kernel<DG, KS>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
+      vae_set_error("conv3_wide_bf16: cannot reserve %d bytes of LDS", LDS_BYTES);
+      return VAE_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  dim3 grid((unsigned)std::min<int64_t>(nt, 256));  // persistent: one 4-wave workgroup per CU
+  hipLaunchKernelGGL(kern, grid, dim3(NT), LDS_BYTES, st, a, tx, ty, (int)nt, kh0, kw0);
+  return 0;
+}
+
 int launch_conv3_wide_bf16(const vae_igemm_args& a, hipStream_t st) {
   const vae_conv_geom& g = a.g;
   const int tx = g.Wo / TW, ty = g.Ho / TH;
   const int64_t nt = (int64_t)((a.N + BN - 1) / BN) * tx * ty * g.B;
-  static bool attr_set[2] = {false, false};
   const bool dg = g.mode == VAE_MODE_DGRAD;
-  if (!attr_set[dg]) {
-    const void* fn = dg ? reinterpret_cast<const void*>(conv3_wide_bf16_kernel<true>) : reinterpret_cast<const void*>(conv3_wide_bf16_kernel<false>);
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
-      vae_set_error("conv3_wide_bf16: cannot reserve %d bytes of LDS", LDS_BYTES);
-      return VAE_ELAUNCH;
-    }
-    attr_set[dg] = true;
+  int kh0 = 0, kw0 = 0;
+  if (a.tapmask != 0) {
+    if (!phase_block(a.tapmask, &kh0, &kw0)) return VAE_EINVAL;
+    return dg ? launch_wide<true, 2>(a, tx, ty, nt, kh0, kw0, st) : launch_wide<false, 2>(a, tx, ty, nt, kh0, kw0, st);
   }
-  dim3 grid((unsigned)std::min<int64_t>(nt, 256));  // persistent: one 4-wave workgroup per CU
-  if (dg) hipLaunchKernelGGL(conv3_wide_bf16_kernel<true>, grid, dim3(NT), LDS_BYTES, st, a, tx, ty, (int)nt);
-  else hipLaunchKernelGGL(conv3_wide_bf16_kernel<false>, grid, dim3(NT), LDS_BYTES, st, a, tx, ty, (int)nt);
-  return 0;
+  return dg ? launch_wide<true, 3>(a, tx, ty, nt, 0, 0, st) : launch_wide<false, 3>(a, tx, ty, nt, 0, 0, st);
 }

@@ -792,7 +792,7 @@ extern "C" int vae_conv_phase_ok(const vae_igemm_args* ap) {
   if (!ap) return 0;
   const vae_igemm_args& a = *ap;
   const bool bkm = rows_bkm(a), vec = rows_vec(a, bkm);
-  if (a.A16 != nullptr) return 0;
+  if (a.A16 != nullptr) return rows_use_wide_bf16(a, vec, bkm) ? 1 : 0;  // operand image: the wide-tile kernel's 2x2 tap blocks
   if (a.prec == VAE_PREC_BF16) return (a.xf == VAE_XF_NONE && rows_use_tile_bf16(a, vec, bkm)) ? 1 : 0;  // no transform variant there
   return rows_use_tile(a, vec, bkm) ? 1 : 0;
 }
@@ -813,7 +813,9 @@ extern "C" int vae_igemm_kernel_name(const vae_igemm_args* ap, char* buf, int32_
   const vae_igemm_args& a = *ap;
   const bool bkm = rows_bkm(a), vec = rows_vec(a, bkm);
   const char* tf[2] = {"false", "true"};
-  if (rows_is_phase(a) && a.prec == VAE_PREC_BF16)
+  if (rows_is_phase(a) && rows_use_wide_bf16(a, vec, bkm))
+    snprintf(buf, n, "conv3_wide_bf16_kernel<%s,2>", tf[a.g.mode == VAE_MODE_DGRAD]);
+  else if (rows_is_phase(a) && a.prec == VAE_PREC_BF16)
     snprintf(buf, n, "conv3_tile_bf16_kernel<%s,%s,%d,false>", tf[a.g.mode == VAE_MODE_DGRAD], tf[a.g.mode == VAE_MODE_UP2X], a.xf);
   else if (rows_is_phase(a))
     snprintf(buf, n, "conv3_tile_kernel<%s,%s,%s,%d>", tf[bkm], tf[a.g.mode == VAE_MODE_DGRAD], tf[a.g.mode == VAE_MODE_UP2X], a.xf);
@@ -822,7 +824,7 @@ extern "C" int vae_igemm_kernel_name(const vae_igemm_args* ap, char* buf, int32_
   else if (conv_smalln_eligible(a))
     snprintf(buf, n, "conv_smalln_kernel<%d>", a.xf);
   else if (rows_use_wide_bf16(a, vec, bkm))
-    snprintf(buf, n, "conv3_wide_bf16_kernel<%s>", tf[a.g.mode == VAE_MODE_DGRAD]);
+    snprintf(buf, n, "conv3_wide_bf16_kernel<%s,3>", tf[a.g.mode == VAE_MODE_DGRAD]);
   else if (rows_use_tile_bf16(a, vec, bkm))
     snprintf(buf, n, "conv3_tile_bf16_kernel<%s,%s,%d,%s>", tf[a.g.mode == VAE_MODE_DGRAD], tf[a.g.mode == VAE_MODE_UP2X], a.xf,
              tf[a.A16 != nullptr]);
@@ -875,6 +877,12 @@ extern "C" int vae_igemm_rows(const vae_igemm_args* ap, void* stream) {
   if (rows_is_phase(a)) {  // sub-sampled views / tap subsets: only the fp32 halo-tile kernel implements them
     VAE_CHECK(vae_conv_phase_ok(ap), "igemm_rows: tapmask / a_step / c_step need a halo-tile kernel (vae_conv_phase_ok)");
     VAE_CHECK(a.track == nullptr && a.gstat == nullptr, "igemm_rows: no tracker / statistics epilogue on a sub-sampled output");
+    if (rows_use_wide_bf16(a, vec, bkm)) {
+      if (int rc2 = launch_conv3_wide_bf16(a, st)) return rc2;
+      VAE_LAUNCH_CHECK("conv3_wide_bf16");
+      return VAE_OK;
+    }
+    VAE_CHECK(a.A16 == nullptr, "igemm_rows: a sub-sampled view of an operand image needs the wide-tile kernel (vae_conv_phase_ok)");
     if (int rc2 = (a.prec == VAE_PREC_BF16) ? launch_conv3_tile_bf16(a, bkm, st) : launch_conv3_tile(a, bkm, st)) return rc2;
     VAE_LAUNCH_CHECK("conv3_tile");
     return VAE_OK;

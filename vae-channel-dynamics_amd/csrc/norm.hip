@@ -303,26 +303,35 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __rest
   }
 }
 
-// stage 2b (same launch as 2a, workgroups B .. B + ceil(C/256) - 1): dgamma/dbeta = sum over batch items and chunks of the
-// stage-1 partials, chunk order inside a batch item, then batch order -- exactly the sums stage 2a forms per batch item
-// (it cannot read 2a's totals: the two roles run concurrently)
+// stage 2b (same launch as 2a, workgroups B ..): dgamma/dbeta = sum over batch items and chunks of the stage-1 partials.
+// A workgroup takes 32 channels; 8 threads per channel split the B * nchunk rows (row r to thread r % 8), fp64, and
+// thread 0 of a channel adds the 8 partial sums in order: a fixed association.  (It cannot use 2a's per-image totals:
+// the two roles run concurrently.)
 __device__ __forceinline__ void gn_bwd_dparam_role(const float* __restrict__ ws, int blk, int B, int C, int nchunk,
-                                                   float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int c = blk * 256 + threadIdx.x;
-  if (c >= C) return;
+                                                   float* __restrict__ dgamma, float* __restrict__ dbeta, double* red /*[2][256]*/) {
+  const int cl = threadIdx.x & 31, part = threadIdx.x >> 5;
+  const int c = blk * 32 + cl;
   double a1 = 0.0, a2 = 0.0;
-  for (int b = 0; b < B; ++b) {
-    double b1 = 0.0, b2 = 0.0;
-    for (int k = 0; k < nchunk; ++k) {
-      const float* o = ws + (((int64_t)b * nchunk + k) * C + c) * 2;
-      b1 += (double)o[0];
-      b2 += (double)o[1];
+  if (c < C) {
+    const int rows = B * nchunk;
+    for (int r = part; r < rows; r += 8) {
+      const float* o = ws + ((int64_t)r * C + c) * 2;
+      a1 += (double)o[0];
+      a2 += (double)o[1];
     }
-    a1 += (double)(float)b1;  // 2a rounds a batch item's total to fp32 before it is used: the same value here
-    a2 += (double)(float)b2;
   }
-  dbeta[c] = (float)a1;
-  dgamma[c] = (float)a2;
+  red[threadIdx.x] = a1;
+  red[256 + threadIdx.x] = a2;
+  __syncthreads();
+  if (part == 0 && c < C) {
+#pragma unroll
+    for (int j = 1; j < 8; ++j) {
+      a1 += red[j * 32 + cl];
+      a2 += red[256 + j * 32 + cl];
+    }
+    dbeta[c] = (float)a1;
+    dgamma[c] = (float)a2;
+  }
 }
 
 // stage 2a: one workgroup per batch item: chunk totals per (b,c) and the group coefficients
@@ -330,9 +339,10 @@ __global__ __launch_bounds__(256) void gn_bwd_final_kernel(const float* __restri
                                                            const float* __restrict__ gamma, int B, int HW, int C, int G,
                                                            int nchunk, float* __restrict__ coef, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta) {
-  __shared__ float sg1[1024], sg2[1024];
+  __shared__ __attribute__((aligned(16))) float sg1[1024];
+  __shared__ float sg2[1024];
   if ((int)blockIdx.x >= B) {  // uniform per workgroup
-    gn_bwd_dparam_role(ws, blockIdx.x - B, B, C, nchunk, dgamma, dbeta);
+    gn_bwd_dparam_role(ws, blockIdx.x - B, B, C, nchunk, dgamma, dbeta, reinterpret_cast<double*>(sg1));  // 512 doubles = sizeof(sg1)
     return;
   }
   const int cpg = C / G;
@@ -495,7 +505,7 @@ extern "C" int vae_gn_bwd_final(const float* ws, const float* rstd, const float*
   if (int e = check_gn("gn_bwd_final", B, HW, C, G, nchunk)) return e;
   VAE_CHECK(ws && rstd && gamma && dgamma && dbeta && coef, "gn_bwd_final: null pointer");
   VAE_CHECK(C <= 1024, "gn_bwd_final: C > 1024");
-  hipLaunchKernelGGL(gn_bwd_final_kernel, dim3(B + (C + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, rstd, gamma, B, HW, C, G,
+  hipLaunchKernelGGL(gn_bwd_final_kernel, dim3(B + (C + 31) / 32), dim3(256), 0, (hipStream_t)stream, ws, rstd, gamma, B, HW, C, G,
                      nchunk, coef, dgamma, dbeta);
   VAE_LAUNCH_CHECK("gn_bwd_final");
   return VAE_OK;

@@ -274,7 +274,18 @@ def _upconv_phase_fwd(x, wv, bias):
     a.C, a.bias = _p(out), _p(bias)
     a.c_step = 2
     a.Wh = _wh(wv)  # (eligibility of the bf16 kernel: any aligned image will do for the query)
-    if not lib.query("vae_conv_phase_ok", C.byref(a)):
+    a.tapmask = _phase_tapmask(0, 0)
+    x16 = None
+    if PRECISION == PREC_BF16 and a.Wh is not None and Cs % 8 == 0:
+        # bf16 image of the low-resolution input (a resnet output, no GroupNorm in front): the wide-tile kernel takes the four
+        # phase convolutions as 2x2 tap blocks
+        a.A16 = a.A  # placeholder with the right alignment for the query
+        if lib.query("vae_conv_phase_ok", C.byref(a)):
+            x16 = pack_bf16(x, torch.empty(x.shape, device=x.device, dtype=torch.bfloat16))
+            a.A16 = _p(x16)
+        else:
+            a.A16 = None
+    if x16 is None and not lib.query("vae_conv_phase_ok", C.byref(a)):
         return None
     we, we16 = _phase_weights(wv)
     for pa in (0, 1):
@@ -285,7 +296,7 @@ def _upconv_phase_fwd(x, wv, bias):
     return out
 
 
-def _upconv_phase_dgrad(dy, wv, in_hw):
+def _upconv_phase_dgrad(dy, wv, in_hw, dy16=None):
     """dy [B,2H,2W,Co] -> gradient wrt the LOW-resolution input [B,H,W,Ci] (no high-resolution intermediate), or None"""
     B, Hy, Wy, Co = dy.shape
     H, W = in_hw
@@ -296,7 +307,18 @@ def _upconv_phase_dgrad(dy, wv, in_hw):
     a.C = _p(out)
     a.a_step = 2
     a.Wh = _wh(wv)
-    if not lib.query("vae_conv_phase_ok", C.byref(a)):
+    a.tapmask = _phase_tapmask(0, 0)
+    use16 = False
+    if PRECISION == PREC_BF16 and a.Wh is not None and Co % 8 == 0:
+        a.A16 = a.A
+        use16 = bool(lib.query("vae_conv_phase_ok", C.byref(a)))
+        if use16:
+            if dy16 is None:
+                dy16 = pack_bf16(dy, torch.empty(dy.shape, device=dy.device, dtype=torch.bfloat16))
+            a.A16 = _p(dy16)
+        else:
+            a.A16 = None
+    if not use16 and not lib.query("vae_conv_phase_ok", C.byref(a)):
         return None
     we, we16 = _phase_weights(wv)
     first = True
@@ -380,7 +402,7 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, kind: str, in_hw: Tuple[int, i
     if dy32 is None and not use16:
         raise ValueError("conv_dgrad: a bf16-only gradient reached a layer whose kernels need fp32")
     if kind == "c3up" and PHASE_UPCONV:
-        out = _upconv_phase_dgrad(dy32, wv, in_hw)
+        out = _upconv_phase_dgrad(dy32, wv, in_hw, dy16)
         if out is not None:
             return out
     if kind == "c3up":
