@@ -238,7 +238,7 @@ def main():
             allk = sum(v["flops"] for v in summ.values()) / (tot_ms * 1e-3) / 1e12
             traffic = None  # HBM bytes per launch of this kernel from the committed rocprofv3 --pmc passes (offline)
             try:
-                tfile = "r01_hbm_traffic.json" if args.dtype == "f32" else "r01_hbm_traffic_bf16.json"
+                tfile = "r02_hbm_traffic.json" if args.dtype == "f32" else "r02_hbm_traffic_bf16.json"
                 with open(os.path.join(ROOT, "profiles", tfile)) as f:
                     tk = json.load(f)["kernels"]
                 hit = tk.get(dom[0].replace(" ", ""))
@@ -249,7 +249,7 @@ def main():
             peak = MFMA_F32_PEAK_TFLOPS if "bf16" not in dom[0] else MFMA_BF16_PEAK_TFLOPS
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": traffic,
-                    "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_hbm_traffic*.json)",
+                    "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r02_hbm_traffic*.json)",
                     "algorithmic_flops_per_launch": round(dom[1]["flops"] / dom[1]["launches"]),
                     "kernel": dom[0], "launches": dom[1]["launches"],
                     "avg_launch_ms": round(dom[1]["ms"] / dom[1]["launches"], 4),
@@ -257,7 +257,7 @@ def main():
                     "contraction_ms_per_step": round(tot_ms / args.steps, 2)}
         hbm = None  # step-level HBM rate (north_star: achieved HBM GB/s vs the 8 TB/s roofline), bytes from the committed PMC passes
         try:
-            tfile = "r01_hbm_traffic.json" if args.dtype == "f32" else "r01_hbm_traffic_bf16.json"
+            tfile = "r02_hbm_traffic.json" if args.dtype == "f32" else "r02_hbm_traffic_bf16.json"
             with open(os.path.join(ROOT, "profiles", tfile)) as f:
                 tot = json.load(f).get("total_hbm_bytes_both_steps")
             if tot and B == BATCH_PER_GPU and R == RES and not args.checkpoint_decoder:

@@ -1,16 +1,20 @@
 #!/bin/bash
-# rocprofv3 evidence for one round: kernel-trace stats of bench.py, then FETCH_SIZE / WRITE_SIZE passes (own runs).
-# usage (on the GPU box): bash tools/profile_round.sh <tag> [bench args...]   -> gpurun_out/prof_<tag>_*
-set -e
-R=$GRAFT_REPO_ROOT; TAG=$1; shift
+# Round profile set (GPU box): rocprofv3 kernel stats of the fp32 and bf16 bench, HBM-traffic PMC passes (separate runs,
+# FETCH_SIZE / WRITE_SIZE only), the dead-weight scan.  usage: bash tools/profile_round.sh r02
+set -x
+R=$GRAFT_REPO_ROOT; TAG=${1:-r02}; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_stats -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $R/gpurun_out/prof_${TAG}_stats.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_${TAG}_fetch -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile "$@" > $R/gpurun_out/prof_${TAG}_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_${TAG}_write -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile "$@" > $R/gpurun_out/prof_${TAG}_write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_f32 -o k -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-profile > $O/stats_f32.json 2> $O/stats_f32.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_bf16 -o k -- python3 $R/bench.py --dtype bf16 --steps 4 --warmup 2 --no-cpu-baseline --no-profile > $O/stats_bf16.json 2> $O/stats_bf16.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_dead -o k -- python3 $R/tools/dead_scan_bench.py > $O/dead_scan.json 2> $O/dead_scan.err
+for P in f32 bf16; do
+  for C in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/pmc_${P}_$C -- python3 $R/bench.py --dtype $P --steps 1 --warmup 1 --no-cpu-baseline --no-profile > $O/pmc_${P}_$C.json 2> $O/pmc_${P}_$C.err
+  done
+done
 cd $R
-python3 tools/hbm_traffic.py gpurun_out/prof_${TAG}_fetch gpurun_out/prof_${TAG}_write gpurun_out/prof_${TAG}_hbm_traffic.json
-find gpurun_out/prof_${TAG}_stats -name "*kernel_stats.csv" -exec cp {} gpurun_out/prof_${TAG}_kernel_stats.csv \;
-# the raw per-dispatch traces are large: keep only the summaries
-find gpurun_out/prof_${TAG}_stats gpurun_out/prof_${TAG}_fetch gpurun_out/prof_${TAG}_write -name "*kernel_trace.csv" -delete
-find gpurun_out/prof_${TAG}_fetch gpurun_out/prof_${TAG}_write -name "*counter_collection.csv" -delete
-tail -2 gpurun_out/prof_${TAG}_stats.log
+python3 tools/hbm_traffic.py $O/pmc_f32_FETCH_SIZE $O/pmc_f32_WRITE_SIZE $O/hbm_traffic.json
+python3 tools/hbm_traffic.py $O/pmc_bf16_FETCH_SIZE $O/pmc_bf16_WRITE_SIZE $O/hbm_traffic_bf16.json
+# keep the merged-back volume small: the raw counter CSVs are large
+rm -rf $O/pmc_*_SIZE/*/ 2>/dev/null; find $O -name "*_kernel_trace.csv" -size +20M -delete
+ls -la $O

@@ -92,11 +92,13 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
 
   // ---------------- staging: global -> registers -> LDS, one piece (16 B per thread) at a time ----------------
   // weight stream: the position of the NEXT stage to request (tile, chunk, kernel column)
-  uint4 rw[NW], rh[HI];
+  // two register sets for the weight stream: a set is requested during the first half of stage s and stored during the second
+  // half of stage s+1 (1.5 stages = ~1 us of lead: an L2 hit takes 0.5-0.8 us under load; half a stage was not enough)
+  uint4 rw[2][NW], rh[HI];
   int w_t = first, w_c = 0, w_kw = 0, w_n0 = 0;  // w_kw: column index inside the tap block
   bool w_ok = first < ntiles;
   if (w_ok) w_n0 = decode(first).n0;
-  auto w_load_piece = [&](int i) {  // piece i of the stage at the stream position
+  auto w_load_piece = [&](int set, int i) {  // piece i of the stage at the stream position
     const int kh = i >> 1, rem = tid + NT * (i & 1);
     const int tap = (kh0 + kh) * 3 + kw0 + w_kw, c0 = w_c * BK;
     unsigned off;
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
       const int k = c0 + (rem >> 4), n = w_n0 + (rem & 15) * 8;
       off = (w_ok && k < p.K && n < p.N) ? (unsigned)((k * (int)p.sk + tap * (int)p.st + n) * 2) : BUF_OOB;
     }
-    rw[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsW, off, 0, 0));
+    rw[set][i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsW, off, 0, 0));
   };
   auto w_advance = [&]() {
     if (++w_kw == KS) {
@@ -120,10 +122,10 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
       }
     }
   };
-  auto w_store_piece = [&](int i, u16* sB) {
+  auto w_store_piece = [&](int set, int i, u16* sB) {
     const int rem = tid + NT * (i & 1);
     u16* dst = sB + (i >> 1) * SB1 + (DG ? (rem >> 4) * LDB + (rem & 15) * 8 : (rem >> 2) * LDB + (rem & 3) * 8);
-    *reinterpret_cast<uint4*>(dst) = rw[i];
+    *reinterpret_cast<uint4*>(dst) = rw[set][i];
   };
   // halo stream: the NEXT channel chunk to request
   int h_t = first, h_c = 0;
@@ -180,22 +182,22 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
   // prologue: the first two stages and the first halo into LDS, the third stage into registers
   u16* ringB[3] = {sW, sW + SB, sW + 2 * SB};  // [0] the stage being multiplied, [1] the next one, [2] the one being written
 #pragma unroll
-  for (int i = 0; i < NW; ++i) w_load_piece(i);
+  for (int i = 0; i < NW; ++i) w_load_piece(0, i);
   w_advance();
 #pragma unroll
   for (int i = 0; i < HI; ++i) h_load_piece(i);
   h_advance();
 #pragma unroll
-  for (int i = 0; i < NW; ++i) w_store_piece(i, ringB[0]);
+  for (int i = 0; i < NW; ++i) w_store_piece(0, i, ringB[0]);
 #pragma unroll
-  for (int i = 0; i < NW; ++i) w_load_piece(i);
+  for (int i = 0; i < NW; ++i) w_load_piece(0, i);
   w_advance();
 #pragma unroll
   for (int i = 0; i < HI; ++i) h_store_piece(i, sHalo);
 #pragma unroll
-  for (int i = 0; i < NW; ++i) w_store_piece(i, ringB[1]);
+  for (int i = 0; i < NW; ++i) w_store_piece(0, i, ringB[1]);
 #pragma unroll
-  for (int i = 0; i < NW; ++i) w_load_piece(i);
+  for (int i = 0; i < NW; ++i) w_load_piece(1, i);  // the third stage: stored during the second half of the first stage
   w_advance();
   __syncthreads();
 #pragma unroll
@@ -208,11 +210,12 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
   // (piece index pi = kg * NPK + q of 2 NPK):
   //   every piece        fragment q of A (the last piece also the remaining slots) and of B for the next k-group
   //                      (k-group 1: of the NEXT stage)
-  //   pi < NW            store piece pi of weight stage +2 (requested a stage ago) into the ring slot that stage -1 used
-  //   pi >= 2 NPK - NW   request a piece of weight stage +3
+  //   pi < NW            request a piece of weight stage +3 into register set PAR
+  //   pi >= 2 NPK - NW   store a piece of weight stage +2 (set PAR^1, requested 1.5 stages ago) into the ring slot stage -1 used
   //   KWI == 0           the first HI pieces request the next chunk's halo;  KWI == 1  the last HI pieces store it
-  auto stage = [&](auto kw_c) {
+  auto stage = [&](auto kw_c, auto par_c) {
     constexpr int KWI = decltype(kw_c)::value;
+    constexpr int PAR = decltype(par_c)::value;  // parity of the stage counter: which weight register set is requested
     constexpr int KWN = (KWI + 1) % KS;
     const u16* sH = sHalo + hpar * SH;
     const u16* sHn = (KWI == KS - 1) ? sHalo + (hpar ^ 1) * SH : sH;  // the next stage's halo buffer
@@ -249,8 +252,8 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
           }
           fetch_b(fb[0], q, sBn, 0);
         }
-        if (pi < NW) w_store_piece(pi, sBw);
-        if (pi >= 2 * NPK - NW) w_load_piece(pi - (2 * NPK - NW));
+        if (pi < NW) w_load_piece(PAR, pi);                                       // stage +3
+        if (pi >= 2 * NPK - NW) w_store_piece(PAR ^ 1, pi - (2 * NPK - NW), sBw);  // stage +2, requested a stage and a half ago
         if (KWI == 0 && pi < HI) h_load_piece(pi);
         if (KWI == 1 && pi >= 2 * NPK - HI) h_store_piece(pi - (2 * NPK - HI), sHw);
         __builtin_amdgcn_sched_barrier(0);
@@ -272,12 +275,26 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
   constexpr std::integral_constant<int, 1> kw1_c{};
   constexpr std::integral_constant<int, 2> kw2_c{};
 
+  constexpr std::integral_constant<int, 0> p0{};
+  constexpr std::integral_constant<int, 1> p1{};
   while (true) {
-    for (int c = 0; c < nch; ++c) {
-      stage(kw0_c);
-      stage(kw1_c);
-      if constexpr (KS == 3) stage(kw2_c);
-      hpar ^= 1;
+    if constexpr (KS == 3) {  // 3 stages per chunk: the stage parity repeats every 2 chunks (the launcher checks nch % 2 == 0)
+      for (int c = 0; c < nch; c += 2) {
+        stage(kw0_c, p0);
+        stage(kw1_c, p1);
+        stage(kw2_c, p0);
+        hpar ^= 1;
+        stage(kw0_c, p1);
+        stage(kw1_c, p0);
+        stage(kw2_c, p1);
+        hpar ^= 1;
+      }
+    } else {
+      for (int c = 0; c < nch; ++c) {
+        stage(kw0_c, p0);
+        stage(kw1_c, p1);
+        hpar ^= 1;
+      }
     }
 
     // ---------------- epilogue ----------------
@@ -429,7 +446,7 @@ bool conv3_wide_bf16_eligible(const vae_igemm_args& a) {
   }
   const size_t as = a.a_step > 1 ? a.a_step : 1, cs = a.c_step > 1 ? a.c_step : 1;
   if (!(g.mode == VAE_MODE_FWD || g.mode == VAE_MODE_DGRAD) || g.Ho != g.Hs || g.Wo != g.Ws) return false;
-  if (g.Wo % TW != 0 || g.Ho % TH != 0 || a.K % 8 != 0 || a.N % 8 != 0 || a.N <= 32 || g.Cs % 8 != 0 || a.st % 8 != 0) return false;
+  if (g.Wo % TW != 0 || g.Ho % TH != 0 || a.K % (2 * BK) != 0 || a.N % 8 != 0 || a.N <= 32 || g.Cs % 8 != 0 || a.st % 8 != 0) return false;
   if (g.mode == VAE_MODE_FWD && !(a.sk == 1 && a.sn % 8 == 0)) return false;
   if (g.mode == VAE_MODE_DGRAD && !(a.sn == 1 && a.sk % 8 == 0)) return false;
   if (a.out_bf16 && (a.bias || a.res || a.track || a.gstat || a.ldc % 2 != 0)) return false;

@@ -697,7 +697,7 @@ extern "C" int vae_wgrad_plan(const vae_wgrad_args* ap, int32_t* nsplit, int32_t
     *xf_fusable = 1;
     return VAE_OK;
   }
-  if (!wgrad_is_phase(a) && wgrad_use_tile_bf16(a)) {
+  if (wgrad_use_tile_bf16(a) && (!wgrad_is_phase(a) || a.prec == VAE_PREC_BF16)) {
     const int64_t units = wgrad3_tile_bf16_units(a.g);
     const int64_t cols = wgrad3_tile_bf16_columns(a);
     int64_t ns = std::max<int64_t>(1, std::min<int64_t>(256 / std::max<int64_t>(cols, 1), units / 4));
@@ -843,7 +843,9 @@ extern "C" int vae_wgrad_kernel_name(const vae_wgrad_args* ap, char* buf, int32_
   const vae_wgrad_args& a = *ap;
   const bool vec = wgrad_vec(a);
   const char* tf[2] = {"false", "true"};
-  if (wgrad_is_phase(a)) snprintf(buf, n, "wgrad3_tile_kernel<%s,%d>", tf[a.g.mode == VAE_MODE_UP2X], a.xf);
+  if (wgrad_is_phase(a) && a.prec == VAE_PREC_BF16)
+    snprintf(buf, n, "wgrad3_tile_bf16_kernel<false,%d,%s,%s>", a.xf, tf[a.X16 != nullptr], tf[a.dY16 != nullptr]);
+  else if (wgrad_is_phase(a)) snprintf(buf, n, "wgrad3_tile_kernel<%s,%d>", tf[a.g.mode == VAE_MODE_UP2X], a.xf);
   else if (wgrad_smallk_kind(a)) snprintf(buf, n, "wgrad_smallk_kernel<%s,%d>", tf[wgrad_smallk_kind(a) == 1], a.xf);
   else if (wgrad_use_tile_bf16(a)) snprintf(buf, n, "wgrad3_tile_bf16_kernel<%s,%d,%s,%s>", tf[a.g.mode == VAE_MODE_UP2X], a.xf, tf[a.X16 != nullptr], tf[a.dY16 != nullptr]);
   else if (wgrad_use_tile(a)) snprintf(buf, n, "wgrad3_tile_kernel<%s,%d>", tf[a.g.mode == VAE_MODE_UP2X], a.xf);
@@ -933,14 +935,16 @@ extern "C" int vae_igemm_rows(const vae_igemm_args* ap, void* stream) {
 }
 
 extern "C" int vae_wgrad_phase_ok(const vae_wgrad_args* ap) {
-  return (ap && ap->prec != VAE_PREC_BF16 && ap->X16 == nullptr && wgrad_use_tile(*ap) && !wgrad_smallk_kind(*ap)) ? 1 : 0;
+  if (!ap || wgrad_smallk_kind(*ap)) return 0;
+  if (ap->prec == VAE_PREC_BF16) return (ap->xf == VAE_XF_NONE && wgrad_use_tile_bf16(*ap)) ? 1 : 0;  // the bf16 halo-tile kernel
+  return (ap->X16 == nullptr && wgrad_use_tile(*ap)) ? 1 : 0;
 }
 extern "C" int vae_wgrad(const vae_wgrad_args* ap, void* stream) {
   VAE_CHECK(ap != nullptr, "wgrad: null args");
   const vae_wgrad_args& a = *ap;
   if (int e = check_geom("wgrad", a.g)) return e;
   VAE_CHECK((a.dY || a.dY16) && a.X, "wgrad: null operand");
-  VAE_CHECK(a.dY16 == nullptr || (wgrad_use_tile_bf16(a) && !wgrad_is_phase(a) && !(a.X16 == nullptr && wgrad_smallk_kind(a)) && aligned16(a.dY16) && a.ldy % 8 == 0 && a.M % 8 == 0),
+  VAE_CHECK(a.dY16 == nullptr || (wgrad_use_tile_bf16(a) && !(a.X16 == nullptr && wgrad_smallk_kind(a)) && aligned16(a.dY16) && a.ldy % 8 == 0 && a.M % 8 == 0),
             "wgrad: dY16 needs bf16 mode and a layer vae_bf16_grad_image_ok accepts");
   VAE_CHECK(a.M > 0 && a.N > 0 && a.npix > 0 && a.nsplit > 0 && a.batch > 0, "wgrad: bad sizes");
   VAE_CHECK(a.N <= a.g.Cs, "wgrad: N exceeds source channels");
@@ -953,9 +957,16 @@ extern "C" int vae_wgrad(const vae_wgrad_args* ap, void* stream) {
   const bool vec = wgrad_vec(a);
   hipStream_t st = (hipStream_t)stream;
   VAE_CHECK(a.prec == VAE_PREC_F32 || a.prec == VAE_PREC_BF16, "wgrad: bad prec %d", a.prec);
-  if (wgrad_is_phase(a)) {  // sub-sampled dY / tap subsets: only the fp32 halo-tile kernel implements them
-    VAE_CHECK(vae_wgrad_phase_ok(ap), "wgrad: tapmask / y_step need the fp32 halo-tile kernel (vae_wgrad_phase_ok)");
+  if (wgrad_is_phase(a)) {  // sub-sampled dY / tap subsets: the halo-tile kernels implement them
+    VAE_CHECK(vae_wgrad_phase_ok(ap), "wgrad: tapmask / y_step need a halo-tile kernel (vae_wgrad_phase_ok)");
     VAE_CHECK(a.nsplit <= 65535, "wgrad: nsplit too large");
+    if (a.prec == VAE_PREC_BF16) {
+      VAE_CHECK(a.X16 == nullptr || (aligned16(a.X16) && a.g.Cs % 8 == 0), "wgrad: unaligned X16");
+      VAE_CHECK(a.dY16 == nullptr || (aligned16(a.dY16) && a.ldy % 8 == 0 && a.M % 8 == 0), "wgrad: unaligned dY16");
+      if (int rc2 = launch_wgrad3_tile_bf16(a, st)) return rc2;
+      VAE_LAUNCH_CHECK("wgrad3_tile_bf16");
+      return VAE_OK;
+    }
     if (int rc2 = launch_wgrad3_tile(a, st)) return rc2;
     VAE_LAUNCH_CHECK("wgrad3_tile");
     return VAE_OK;

@@ -304,17 +304,17 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __rest
 }
 
 // stage 2b (same launch as 2a, workgroups B ..): dgamma/dbeta = sum over batch items and chunks of the stage-1 partials.
-// A workgroup takes 32 channels; 8 threads per channel split the B * nchunk rows (row r to thread r % 8), fp64, and
-// thread 0 of a channel adds the 8 partial sums in order: a fixed association.  (It cannot use 2a's per-image totals:
+// A workgroup takes 8 channels; 32 threads per channel split the B * nchunk rows (row r to thread r % 32), fp64, and
+// thread 0 of a channel adds the 32 partial sums in order: a fixed association.  (It cannot use 2a's per-image totals:
 // the two roles run concurrently.)
 __device__ __forceinline__ void gn_bwd_dparam_role(const float* __restrict__ ws, int blk, int B, int C, int nchunk,
                                                    float* __restrict__ dgamma, float* __restrict__ dbeta, double* red /*[2][256]*/) {
-  const int cl = threadIdx.x & 31, part = threadIdx.x >> 5;
-  const int c = blk * 32 + cl;
+  const int cl = threadIdx.x & 7, part = threadIdx.x >> 3;
+  const int c = blk * 8 + cl;
   double a1 = 0.0, a2 = 0.0;
   if (c < C) {
     const int rows = B * nchunk;
-    for (int r = part; r < rows; r += 8) {
+    for (int r = part; r < rows; r += 32) {
       const float* o = ws + ((int64_t)r * C + c) * 2;
       a1 += (double)o[0];
       a2 += (double)o[1];
@@ -324,10 +324,10 @@ __device__ __forceinline__ void gn_bwd_dparam_role(const float* __restrict__ ws,
   red[256 + threadIdx.x] = a2;
   __syncthreads();
   if (part == 0 && c < C) {
-#pragma unroll
-    for (int j = 1; j < 8; ++j) {
-      a1 += red[j * 32 + cl];
-      a2 += red[256 + j * 32 + cl];
+#pragma unroll 8
+    for (int j = 1; j < 32; ++j) {
+      a1 += red[j * 8 + cl];
+      a2 += red[256 + j * 8 + cl];
     }
     dbeta[c] = (float)a1;
     dgamma[c] = (float)a2;
@@ -505,7 +505,7 @@ extern "C" int vae_gn_bwd_final(const float* ws, const float* rstd, const float*
   if (int e = check_gn("gn_bwd_final", B, HW, C, G, nchunk)) return e;
   VAE_CHECK(ws && rstd && gamma && dgamma && dbeta && coef, "gn_bwd_final: null pointer");
   VAE_CHECK(C <= 1024, "gn_bwd_final: C > 1024");
-  hipLaunchKernelGGL(gn_bwd_final_kernel, dim3(B + (C + 31) / 32), dim3(256), 0, (hipStream_t)stream, ws, rstd, gamma, B, HW, C, G,
+  hipLaunchKernelGGL(gn_bwd_final_kernel, dim3(B + (C + 7) / 8), dim3(256), 0, (hipStream_t)stream, ws, rstd, gamma, B, HW, C, G,
                      nchunk, coef, dgamma, dbeta);
   VAE_LAUNCH_CHECK("gn_bwd_final");
   return VAE_OK;

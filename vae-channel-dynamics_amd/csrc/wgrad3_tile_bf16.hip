@@ -52,6 +52,11 @@ __global__ __launch_bounds__(NT) void wgrad3_tile_bf16_kernel(vae_wgrad_args p, 
   const int Hb = UP ? 2 * g.Hs : g.Hs, Wb = UP ? 2 * g.Ws : g.Ws;
   const bool do_bias = (p.bias_partial != nullptr) && tn == 0;
   const int units_per_img = tiles_x * tiles_y;
+  // phase convolutions of an upsampler (vaehip.h): dY is a sub-sampled view (pixel (y,x) at (y*ys+y_oy, x*ys+y_ox)) and only the
+  // taps of tapmask are computed -- a wave whose kernel row is masked out only helps with the staging, the others skip the
+  // masked columns (their accumulators stay zero and are written as zeros)
+  const int ys = (!UP && p.y_step > 1) ? p.y_step : 1;
+  const int wmask = ((p.tapmask ? p.tapmask : 0x1ff) >> (3 * tg)) & 7;
 
   const int b_lo = nu > 0 ? (int)(ubeg / units_per_img) : 0;
   if (XF != VAE_XF_NONE && nu > 0) {
@@ -114,22 +119,23 @@ __global__ __launch_bounds__(NT) void wgrad3_tile_bf16_kernel(vae_wgrad_args p, 
     // buffer descriptors (common.h) over this unit's image of dY and of X: out-of-range offsets read zeros
     const auto rsX = VAE_BUF_RSRC(p.X + (int64_t)b * g.Hs * g.Ws * g.Cs, (size_t)g.Hs * g.Ws * g.Cs * 4u);
     if (Y16) {
-      const auto rsY16 = VAE_BUF_RSRC(reinterpret_cast<const u16*>(p.dY16) + (int64_t)b * g.Ho * g.Wo * p.ldy, (size_t)g.Ho * g.Wo * p.ldy * 2u);
+      const auto rsY16 = VAE_BUF_RSRC(reinterpret_cast<const u16*>(p.dY16) + (int64_t)b * (g.Ho * ys) * (g.Wo * ys) * p.ldy,
+                                      (size_t)(g.Ho * ys) * (g.Wo * ys) * p.ldy * 2u);
       const int AQ16v = valid ? AQ16 : 0;
 #pragma unroll
       for (int i = 0; i < AI16; ++i) {
         const int q = tid + NT * i;
         const int px = q >> 4, c = m0 + (q & 15) * 8;
-        const int pix = (y0 + (px >> 5)) * g.Wo + x0 + (px & 31);
+        const int pix = ((y0 + (px >> 5)) * ys + p.y_oy) * (g.Wo * ys) + (x0 + (px & 31)) * ys + p.y_ox;
         ra16[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsY16, (q < AQ16v && c < p.M) ? (unsigned)((pix * p.ldy + c) * 2) : BUF_OOB, 0, 0));
       }
     } else {
-      const auto rsY = VAE_BUF_RSRC(p.dY + (int64_t)b * g.Ho * g.Wo * p.ldy, (size_t)g.Ho * g.Wo * p.ldy * 4u);
+      const auto rsY = VAE_BUF_RSRC(p.dY + (int64_t)b * (g.Ho * ys) * (g.Wo * ys) * p.ldy, (size_t)(g.Ho * ys) * (g.Wo * ys) * p.ldy * 4u);
 #pragma unroll
       for (int i = 0; i < (Y16 ? 1 : AI); ++i) {
         const int q = tid + NT * i;
         const int px = q >> 5;  // 0..63 : (row px>>5, col px&31)
-        const int pix = (y0 + (px >> 5)) * g.Wo + x0 + (px & 31);
+        const int pix = ((y0 + (px >> 5)) * ys + p.y_oy) * (g.Wo * ys) + (x0 + (px & 31)) * ys + p.y_ox;
         const int c = m0 + a4 * 4;
         ra[i] = VAE_BUF_LOAD4(rsY, (q < AQv && c < p.M) ? (unsigned)((pix * p.ldy + c) * 4) : BUF_OOB);
       }
@@ -240,9 +246,11 @@ __global__ __launch_bounds__(NT) void wgrad3_tile_bf16_kernel(vae_wgrad_args p, 
         fb[(grp + 1) & 1] = fetch_b(sH, grp + 1);
       }
       __builtin_amdgcn_sched_barrier(0);
+      if ((wmask >> t) & 1) {  // uniform per wave (always true without a tap mask)
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-        acc[t][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kg & 1][mi], fb[grp & 1], acc[t][mi], 0, 0, 0);
+        for (int mi = 0; mi < 2; ++mi)
+          acc[t][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kg & 1][mi], fb[grp & 1], acc[t][mi], 0, 0, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -322,7 +330,9 @@ bool wgrad3_tile_bf16_eligible(const vae_wgrad_args& a, bool vec) {
   if (g.mode == VAE_MODE_FWD && !(g.Ho == g.Hs && g.Wo == g.Ws)) return false;
   if (g.mode == VAE_MODE_UP2X && !(g.Ho == 2 * g.Hs && g.Wo == 2 * g.Ws)) return false;
   if (g.mode == VAE_MODE_DGRAD) return false;
-  if ((size_t)g.Ho * g.Wo * a.ldy * 4u >= BUF_MAX || (size_t)g.Hs * g.Ws * g.Cs * 4u >= BUF_MAX) return false;  // one image per descriptor
+  const size_t ys = a.y_step > 1 ? a.y_step : 1;
+  if ((ys > 1 || a.tapmask != 0) && g.mode != VAE_MODE_FWD) return false;
+  if ((size_t)g.Ho * g.Wo * a.ldy * 4u * ys * ys >= BUF_MAX || (size_t)g.Hs * g.Ws * g.Cs * 4u >= BUF_MAX) return false;  // one image per descriptor
   return true;
 }
 int64_t wgrad3_tile_bf16_units(const vae_conv_geom& g) { return (int64_t)g.B * (g.Ho / TH) * (g.Wo / TW); }

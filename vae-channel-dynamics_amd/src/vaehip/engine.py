@@ -359,11 +359,11 @@ class Engine:
             tape.append(bwd)
         return out
 
-    def _mid(self, mb, x, tape):
+    def _mid(self, mb, x, tape, after_conv3=False):
         self._pre(mb, lambda: x)
         # registration order (attentions, resnets) differs from execution order, so the DP watermark
         # only moves once the whole mid block is final: after resnets[0]'s backward (last on the tape)
-        h = self._seg(lambda t, tp: self._resnet(mb.resnets[0], t, tp, notify=mb), x, tape)
+        h = self._seg(lambda t, tp: self._resnet(mb.resnets[0], t, tp, notify=mb, after_conv3=after_conv3), x, tape)
         h = self._seg(lambda t, tp: self._attention(mb.attentions[0], t, tp, notify=False, after_conv3=True), h, tape)
         h = self._seg(lambda t, tp: self._resnet(mb.resnets[1], t, tp, notify=False), h, tape)
         self._post(mb, lambda: x, h)
@@ -375,11 +375,13 @@ class Engine:
         self._post(s, lambda: x, y)
         return y
 
-    def _updown_block(self, blk, x, tape):
+    def _updown_block(self, blk, x, tape, first_after_conv3=False):
+        """first_after_conv3: the block's input is the output of a 3x3 stride-1 convolution (a resnet's conv2 or an upsampler's
+        convolution), so the gradient that leaves the block is worth a bf16 image too"""
         self._pre(blk, lambda: x)
         h = x
         for i, r in enumerate(blk.resnets):  # a resnet after the first one continues the output of the previous one's conv2
-            h = self._seg(lambda t, tp, r=r, i=i: self._resnet(r, t, tp, after_conv3=i > 0), h, tape)
+            h = self._seg(lambda t, tp, r=r, i=i: self._resnet(r, t, tp, after_conv3=(i > 0 or first_after_conv3)), h, tape)
         extra = getattr(blk, "downsamplers", None) or getattr(blk, "upsamplers", None)
         if extra is not None:
             h = self._seg(lambda t, tp: self._sampler(extra[0], t, tp), h, tape)
@@ -409,7 +411,7 @@ class Engine:
         h = self._plain_conv(enc.conv_in, x4, tape, need_dx=False)
         for blk in enc.down_blocks:
             h = self._updown_block(blk, h, tape)
-        h = self._mid(enc.mid_block, h, tape)
+        h = self._mid(enc.mid_block, h, tape, after_conv3=True)  # behind down_blocks[-1]'s last resnet
         h = self._norm_act_conv(enc, h, tape)
         self._post(enc, lambda: x4[..., :3], h)
         return h
@@ -424,8 +426,8 @@ class Engine:
         try:
             h = self._plain_conv(dec.conv_in, z, tape)
             h = self._mid(dec.mid_block, h, tape)
-            for blk in dec.up_blocks:
-                h = self._updown_block(blk, h, tape)
+            for blk in dec.up_blocks:  # behind the mid block's last resnet / the previous block's upsampler convolution
+                h = self._updown_block(blk, h, tape, first_after_conv3=True)
             h = self._norm_act_conv(dec, h, tape)
         finally:
             self._ckpt = False

@@ -283,6 +283,7 @@ def _upconv_phase_fwd(x, wv, bias):
         if lib.query("vae_conv_phase_ok", C.byref(a)):
             x16 = pack_bf16(x, torch.empty(x.shape, device=x.device, dtype=torch.bfloat16))
             a.A16 = _p(x16)
+            x._b16 = x16  # the layer's weight gradient reads the same image
         else:
             a.A16 = None
     if x16 is None and not lib.query("vae_conv_phase_ok", C.byref(a)):
@@ -442,9 +443,10 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, kind: str, in_hw: Tuple[int, i
     return out
 
 
-def _upconv_phase_wgrad(dy, x, gv, bgrad_out) -> bool:
+def _upconv_phase_wgrad(dy, x, gv, bgrad_out, dy16=None) -> bool:
     """weight (and bias) gradient of conv3x3(nearest_upsample_2x(x)) from four phase weight gradients on the low-resolution
-    grid (each computes the 4 taps of its 2x2 effective kernel), folded back into the 3x3 gradient; False = not served"""
+    grid (each computes the 4 taps of its 2x2 effective kernel), folded back into the 3x3 gradient; False = not served.
+    bf16 mode: both operands as bf16 images (x at low resolution, dy at high resolution through the strided view)."""
     Co, _, _, Ci = gv.shape
     B, H, W, Cs = x.shape
     if Cs != Ci:
@@ -454,10 +456,20 @@ def _upconv_phase_wgrad(dy, x, gv, bgrad_out) -> bool:
     a.g = ConvGeom(B, H, W, Cs, H, W, 9, 1, 1, 1, MODE_FWD)
     a.M, a.N, a.ldy, a.npix, a.nsplit = Co, Ci, Co, B * H * W, 1
     a.batch, a.sYb, a.sXb, a.sOb = 1, 0, 0, 0
-    a.xf, a.alpha, a.prec = XF_NONE, 1.0, PREC_F32
+    a.xf, a.alpha, a.prec = XF_NONE, 1.0, PRECISION
     a.y_step, a.tapmask = 2, _phase_tapmask(0, 0)
     if not lib.query("vae_wgrad_phase_ok", C.byref(a)):
         return False
+    keep = []
+    if PRECISION == PREC_BF16 and Cs % 8 == 0 and Co % 8 == 0:
+        x16 = getattr(x, "_b16", None)
+        if x16 is None:
+            x16 = pack_bf16(x, torch.empty(x.shape, device=x.device, dtype=torch.bfloat16))
+        if dy16 is None:
+            dy16 = pack_bf16(dy, torch.empty(dy.shape, device=dy.device, dtype=torch.bfloat16))
+            dy._b16 = dy16  # the dgrad that follows reads the same image
+        keep = [x16, dy16]
+        a.X16, a.dY16 = _p(x16), _p(dy16)
     ns, fus = C.c_int32(0), C.c_int32(0)
     lib.call("vae_wgrad_plan", C.byref(a), C.byref(ns), C.byref(fus))
     ns = ns.value
@@ -477,11 +489,14 @@ def _upconv_phase_wgrad(dy, x, gv, bgrad_out) -> bool:
                 a.partial = _p(partial)
             a.bias_partial = _p(bpart)
             _launch_wgrad(a)
-            if ns > 1:
+            if ns > 1 and bpart is not None:
+                lib.call("vae_reduce_splits2", _p(partial), ns, n, _p(dwe[ph]), _p(bpart), Co, _p(dbe[ph]), _stream())
+            elif ns > 1:
                 lib.call("vae_reduce_splits", _p(partial), ns, n, _p(dwe[ph]), _stream())
-            if bpart is not None:
+            elif bpart is not None:
                 lib.call("vae_reduce_splits", _p(bpart), ns, Co, _p(dbe[ph]), _stream())
     lib.call("vae_upconv_fold_wgrad", _p(dwe), _p(dbe), Co, Ci, _p(gv), _p(bgrad_out), _stream())
+    del keep
     return True
 
 
@@ -504,8 +519,8 @@ def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, kind: str, wgrad_out: torch.Te
     B, H, W, Cs = x.shape
     g = _fwd_geom(kind, B, H, W, Cs)
     assert dy.shape == (B, g.Ho, g.Wo, Co), (dy.shape, (B, g.Ho, g.Wo, Co))
-    if (kind == "c3up" and PHASE_UPCONV and PRECISION == PREC_F32 and xf == XF_NONE and x16 is None
-            and _upconv_phase_wgrad(dy32, x, gv, bgrad_out)):
+    if (kind == "c3up" and PHASE_UPCONV and xf == XF_NONE and x16 is None and dy32 is not None
+            and _upconv_phase_wgrad(dy32, x, gv, bgrad_out, dy16)):
         return
     npix = B * g.Ho * g.Wo
     use16 = dy16 is not None and grad_image_ok(kind, x.shape, Co, Ci)
