@@ -120,6 +120,8 @@ def main():
     ap.add_argument("--nudge-interval", type=int, default=0,
                     help="InterventionHandler (gentle nudge x1.10, cap 1.5) every K steps inside the timed loop (BASELINE configs[3]: 100)")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl", help="nccl = RCCL over xGMI (the product path)")
+    ap.add_argument("--one-device", action="store_true",
+                    help="rehearsal on a one-GPU box: every rank uses cuda:0 (needs --dist-backend gloo; RCCL refuses two ranks per device)")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="launch the ranks, form the process group, all-reduce one number and print it: the multi-rank "
                          "plumbing without touching a GPU (CPU test of the launcher, with --dist-backend gloo)")
@@ -146,6 +148,10 @@ def main():
                               "allreduce_sum": float(t.item())}))
         dist.destroy_process_group()
         return
+    if args.one_device:
+        if world > 1 and args.dist_backend != "gloo":
+            raise SystemExit("--one-device needs --dist-backend gloo")
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:

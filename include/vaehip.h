@@ -101,6 +101,8 @@ typedef struct vae_igemm_args {
   float* gstat;          /* optional (vae_conv_gstat_chunks(a) > 0): GroupNorm statistics of the OUTPUT from the epilogue:  */
   int32_t gstat_groups;  /* ws[b][chunk][gstat_groups][2] = (mean, M2) per output tile -- the layout
                           * vae_gn_stats_partial writes, so vae_gn_stats_final finishes it; saves re-reading the output */
+  const float* Wu;       /* optional (prec == F32, vae_wino_ok(a)): the Winograd-transformed weights vae_wino_weights(a, Wu) built from
+                          * W; the 3x3 stride-1 layer then runs as F(2x2,3x3): 16 instead of 36 multiplications per 2x2 outputs */
   int32_t out_bf16;      /* != 0 (vae_conv_out_bf16_ok(a)): C is a bf16 tensor (2 B per element, same [m][ldc] layout): the dgrad
                           * outputs of bf16 mode, read back by vae_gn_bwd_* (g_bf16); no bias / res / track / gstat with it   */
 } vae_igemm_args;
@@ -108,6 +110,13 @@ int vae_igemm_rows(const vae_igemm_args* a, void* stream);
 /* number of chunks per image the launch for `a` (with a->gstat_groups set) would write into a->gstat, or 0 when the
  * kernel serving it has no statistics epilogue (the caller then runs vae_gn_stats_partial on the output)           */
 int vae_conv_gstat_chunks(const vae_igemm_args* a);
+/* Winograd F(2x2,3x3), fp32 forward / dgrad of plain 3x3 stride-1 layers (csrc/conv3_wino.hip).  vae_wino_ok: 1 when the layer
+ * `a` describes (a->Wu ignored) is served; vae_wino_weight_floats: size of the transformed weights (16 * N * K floats);
+ * vae_wino_weights: U = G g G^T of a->W (the dgrad geometry rotates and transposes), layout [K/8][16][N][8], into Wu.
+ * The weights are transformed per launch because they are live (optimizer step, in-place nudges): 9 -> 16 floats per pair. */
+int vae_wino_ok(const vae_igemm_args* a);
+int64_t vae_wino_weight_floats(const vae_igemm_args* a);
+int vae_wino_weights(const vae_igemm_args* a, float* Wu, void* stream);
 /* 1 when the kernel that would serve `a` can write a bf16 output (a->out_bf16): the bf16 halo-tile kernels, dgrad      */
 int vae_conv_out_bf16_ok(const vae_igemm_args* a);
 /* 1 when the kernel that would serve `a` honours tapmask / a_step.. / c_step.. (the halo-tile kernels), else 0     */

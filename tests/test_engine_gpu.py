@@ -147,10 +147,11 @@ def test_foreign_hooks_get_real_tensors(pair):
     for n in names:
         assert got[n][0].shape == ref[n][0].shape and got[n][1].shape == ref[n][1].shape, n
         assert _rel(got[n][0], ref[n][0]) < 1e-4 and _rel(got[n][1], ref[n][1]) < 1e-4, n
-    # hooks removed -> fused path again, same result
+    # hooks removed -> fused path again, same result (a hooked conv runs without the fused residual / statistics epilogue and
+    # may land on another kernel than the fused one -- Winograd vs direct --, so equal to summation accuracy, not bitwise)
     with torch.no_grad():
         out2 = w(x.cuda(), sample_posterior=False)
-    assert _rel(out2["reconstruction"], out["reconstruction"]) < 1e-6
+    assert _rel(out2["reconstruction"], out["reconstruction"]) < 5e-5
 
 
 def test_standalone_submodule_calls(pair):

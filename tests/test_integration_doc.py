@@ -53,7 +53,7 @@ def test_documented_struct_mirrors_match_the_library():
     md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     for path in re.findall(r"--config_path (\S+\.yaml)", md):
         assert os.path.exists(os.path.join(ROOT, path)), path
-    n_exported = len(re.findall(r"^(?:int|const char\*) (vae_\w+)\(", hdr, flags=re.M))
+    n_exported = len(re.findall(r"^(?:int|int64_t|const char\*) (vae_\w+)\(", hdr, flags=re.M))
     design = open(os.path.join(ROOT, "DESIGN.md")).read()
     m = re.search(r"(\d+) entry points, ABI version (\d+)", design)
     assert m and int(m.group(1)) == n_exported and int(m.group(2)) == L.EXPECTED_ABI

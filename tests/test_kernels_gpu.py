@@ -791,3 +791,55 @@ def test_groupnorm_statistics_with_large_mean(cuda, ratio):
     r64 = 1.0 / torch.sqrt(zg.var(-1, unbiased=False) + 1e-6)
     assert float(((st_f.rstd.cpu().double() - r64) / r64).abs().max()) < 2e-5
     assert _rel(st_f.mean, zg.mean(-1)) < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Winograd F(2x2,3x3) (csrc/conv3_wino.hip): fp32 forward (plain, with GroupNorm+SiLU fused on the patch loads, bias, residual)
+# and dgrad against torch's CPU convolution AND against the direct halo-tile kernels (VAEHIP_NO_WINO=1).  The transforms only
+# add / subtract / halve: the result must stay at fp32 summation accuracy.  (6,16,48,...): ragged tile counts, N not a multiple
+# of 128; (2,8,16,128,32): one tile, the smallest N served.
+# ---------------------------------------------------------------------------------------------------------
+WINO_CASES = [(2, 32, 32, 128, 128), (1, 64, 64, 256, 128), (2, 16, 32, 512, 512), (6, 16, 48, 128, 160), (2, 8, 16, 128, 32)]
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co", WINO_CASES)
+def test_winograd_forward_and_dgrad(cuda, B, H, W, Ci, Co):
+    from vaehip import ops
+    gen = torch.Generator().manual_seed(41 + Ci + Co + H)
+    x = torch.randn(B, Ci, H, W, generator=gen) * 1.3 + 0.2
+    w = torch.randn(Co, Ci, 3, 3, generator=gen) / math.sqrt(9 * Ci)
+    bias = torch.randn(Co, generator=gen)
+    res = torch.randn(B, Co, H, W, generator=gen)
+    gamma, beta = 1 + 0.3 * torch.randn(Ci, generator=gen), 0.2 * torch.randn(Ci, generator=gen)
+    xd, wd = _nhwc(x), _to_dev_ohwi(w)
+    st = ops.gn_stats(xd, gamma.cuda(), beta.cuda())
+    dy = torch.randn(B, Co, H, W, generator=gen)
+    prof = ops.PROFILER = ops.LaunchProfiler()
+    try:
+        y0 = ops.conv_fwd(xd, wd, bias.cuda(), "c3")
+        y1 = ops.conv_fwd(xd, wd, bias.cuda(), "c3", xf=ops.XF_AFFINE_SILU, stats=st, res=_nhwc(res), gstat_groups=32)
+        dx = ops.conv_dgrad(_nhwc(dy), wd, "c3", (H, W))
+    finally:
+        ops.PROFILER = None
+    dgk = "conv3_wino_kernel<0>" if Co >= 64 else "igemm_rows_kernel<128,128,4,2,true,true,0>"  # the dgrad contracts over Co
+    assert [r[0] for r in prof.records] == ["conv3_wino_kernel<0>", "conv3_wino_kernel<2>", dgk], [r[0] for r in prof.records]
+    if Co % 128 == 0:  # GroupNorm moments of the output from the epilogue == those of the tensor it wrote
+        assert hasattr(y1, "_gstat") and y1._gstat[2] == (H // 8) * (W // 16)
+        g2, b2 = torch.ones(Co, device="cuda"), torch.zeros(Co, device="cuda")
+        st_f, st_p = ops.gn_stats(y1, g2, b2), ops.gn_stats(y1.clone(), g2, b2)
+        assert _rel(st_f.mean, st_p.mean) < 1e-5 and _rel(st_f.rstd, st_p.rstd) < 1e-5
+    xr = x.clone().requires_grad_(True)
+    ref0 = F.conv2d(xr, w, bias, 1, 1)
+    (gx,) = torch.autograd.grad(ref0, xr, dy)
+    ref1 = F.conv2d(F.silu(F.group_norm(x, 32, gamma, beta, 1e-6)), w, bias, 1, 1) + res
+    assert _rel(_nchw(y0), ref0.detach()) < 1e-5 and _rel(_nchw(y1), ref1) < 2e-5 and _rel(_nchw(dx), gx) < 1e-5
+    os.environ["VAEHIP_NO_WINO"] = "1"
+    try:
+        z0 = ops.conv_fwd(xd, wd, bias.cuda(), "c3")
+        z1 = ops.conv_fwd(xd, wd, bias.cuda(), "c3", xf=ops.XF_AFFINE_SILU, stats=st, res=_nhwc(res))
+        dz = ops.conv_dgrad(_nhwc(dy), wd, "c3", (H, W))
+    finally:
+        del os.environ["VAEHIP_NO_WINO"]
+    assert _rel(y0, z0) < 5e-6 and _rel(y1, z1) < 5e-6 and _rel(dx, dz) < 5e-6 and not torch.equal(y0, z0)
+    # deterministic
+    assert torch.equal(ops.conv_fwd(xd, wd, bias.cuda(), "c3"), y0)

@@ -4,7 +4,7 @@
 set -e
 R=$GRAFT_REPO_ROOT; TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_ACTIVE_INST_LDS --output-format csv -d $R/gpurun_out/pmc_$TAG -- python3 $R/tools/microbench_bf16.py "$@" > $R/gpurun_out/pmc_$TAG.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_ACTIVE_INST_LDS --output-format csv -d $R/gpurun_out/pmc_$TAG -- python3 $R/tools/${MB:-microbench_bf16.py} "$@" > $R/gpurun_out/pmc_$TAG.log 2>&1
 cd $R
 python3 - <<PY
 import csv, glob, collections
@@ -16,7 +16,7 @@ for r in csv.DictReader(open(kt)):
 agg = collections.OrderedDict()
 for r in csv.DictReader(open(f)):
     k = r["Kernel_Name"]
-    if "tile" not in k and "wide" not in k: continue
+    if "tile" not in k and "wide" not in k and "wino" not in k: continue
     key = (k, r.get("Grid_Size", r.get("Grid_Size_X", "")), r.get("LDS_Block_Size", ""), r.get("Dispatch_Id", "0"))
     agg.setdefault(key, collections.defaultdict(list))[r["Counter_Name"]].append(float(r["Counter_Value"]))
 # one line per kernel instantiation: averages over its dispatches

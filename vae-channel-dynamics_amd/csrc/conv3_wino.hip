@@ -1,0 +1,362 @@
+// Winograd F(2x2, 3x3) for the fp32 forward and dgrad of the 3x3 stride-1 layers: 16 multiplications per 2x2 output tile and
+// channel pair instead of 36 (2.25x fewer MFMA passes), exact fp32 products on v_mfma_f32_32x32x2_f32 as everywhere in fp32 mode.
+//     Y = A^T [ sum_ci (G g G^T) (.) (B^T d B) ] A          d: 4x4 input patch, g: 3x3 kernel, Y: 2x2 outputs
+// The element-wise product summed over input channels is, per position (xi, nu) of the 4x4 transform domain, a GEMM
+//     M[pos][tile][co] = sum_ci V[pos][tile][ci] * U[pos][co][ci]
+// so a workgroup runs 16 GEMMs of [32 tiles] x [128 co] over the channel chunks.
+//   * U = G g G^T is built once per launch by vae_wino_weights from the LIVE weights (they change every optimizer step and
+//     the nudger edits parameters in place), laid out [K/8][16][N][8]: a workgroup's slab of one channel chunk is 16
+//     contiguous 4 KB pieces.  For dgrad the kernel is rotated and transposed there (N = Cin, K = Cout).
+//   * Workgroup (8 waves) = 8 x 16 output pixels (32 Winograd tiles) x 128 output channels; channel chunk of 8 per step.
+//     Threads 0..359 load the chunk's 10 x 18 input halo once (GroupNorm + SiLU applied once per element) into LDS two steps
+//     ahead; threads 0..255 each own one (tile, channel) of the chunk, take B^T d B of the 4x4 patch (32 additions) and write
+//     the 16 values into the V image [16][32][8] (double buffered).  Wave w multiplies positions 2w, 2w+1: per position ONE
+//     16-byte A fragment row read covers the chunk (k = 4*half + s over 4 MFMAs) against 4 B fragments (channel blocks):
+//     32 MFMAs per wave and step.
+//   * The B fragment of (position, channel block) is 16 contiguous bytes per lane of the U image, and only the wave that owns
+//     the position needs it: U goes from L2 straight into registers, one step ahead (two register sets), never through LDS.
+//     One barrier per step (it publishes the next V); the two waves of a SIMD run the step in opposite order (stage then
+//     multiply / multiply then stage) so the matrix pipe has work while V is being transformed.
+//   * Epilogue: the 16 positions of an output tile sit in 8 different waves, so the accumulators go through LDS one
+//     32-channel block at a time ([16][32 tiles][32 co], over the V buffers), then each thread takes A^T M A of its
+//     (tile, channel) pairs, adds bias / residual and writes the 2x2 outputs (lanes along channels: 128-byte rows).
+// Numerics: the transforms only add / subtract / halve; measured against the direct kernels 1e-6 of the output scale
+// (tests/test_kernels_gpu.py), far inside the 1e-4 bar.  The epilogue also leaves the GroupNorm centred moments of the outputs
+// (one chunk per workgroup tile, as the direct kernels do); a tracked output stays on the direct kernel.
+#include "common.h"
+#include <algorithm>
+
+namespace {
+
+constexpr int WTH = 8, WTW = 16;          // output pixels per workgroup tile
+constexpr int NTL = 32;                   // Winograd tiles per workgroup (4 rows x 8 columns of 2x2 outputs)
+constexpr int WBK = 8;                    // channels per step
+constexpr int WBN = 128, WNT = 512;
+constexpr int SV = 16 * NTL * WBK;        // floats per V buffer (16384 B): rows of 8 floats, a wave's 16-byte fragment reads
+                                          // cover 1 KB contiguously and the transform's 4-byte writes are thread-contiguous
+constexpr int SMLD = 33;                  // epilogue image row (floats)
+constexpr int SHL = 180 * WBK;            // floats per halo buffer (10 x 18 pixels x 8 channels, 5760 B)
+constexpr int SM = 16 * NTL * SMLD + 8 * 8 * 2;  // epilogue image + statistics scratch; overlays the V / halo buffers
+constexpr int WINO_LDS = (SM > 2 * SV + 2 * SHL ? SM : 2 * SV + 2 * SHL) * 4;  // 68096 B
+
+// U[pos][n][k] = (G g G^T)[pos] for g = W[n][.][.][k] (forward, N = Cout, K = Cin) or g = rot180(W[k][.][.][n]) (dgrad,
+// N = Cin, K = Cout); output layout [K/8][16][N][8]
+__global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restrict__ W, int N, int K, int dgrad, int64_t sn, int64_t sk, int64_t st,
+                                                           float* __restrict__ U) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)N * K) return;
+  const int k = (int)(i % K), n = (int)(i / K);
+  float g[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const int tap = dgrad ? (2 - a) * 3 + (2 - b) : a * 3 + b;
+      g[a][b] = W[(int64_t)n * sn + (int64_t)k * sk + (int64_t)tap * st];
+    }
+  float t[4][3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    t[0][b] = g[0][b];
+    t[1][b] = 0.5f * ((g[0][b] + g[2][b]) + g[1][b]);
+    t[2][b] = 0.5f * ((g[0][b] + g[2][b]) - g[1][b]);
+    t[3][b] = g[2][b];
+  }
+  float* o = U + ((int64_t)(k >> 3) * 16 * N + n) * 8 + (k & 7);
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const float u0 = t[a][0], u3 = t[a][2];
+    const float u1 = 0.5f * ((t[a][0] + t[a][2]) + t[a][1]);
+    const float u2 = 0.5f * ((t[a][0] + t[a][2]) - t[a][1]);
+    o[(int64_t)(a * 4 + 0) * N * 8] = u0;
+    o[(int64_t)(a * 4 + 1) * N * 8] = u1;
+    o[(int64_t)(a * 4 + 2) * N * 8] = u2;
+    o[(int64_t)(a * 4 + 3) * N * 8] = u3;
+  }
+}
+
+template <int XF>
+__global__ __launch_bounds__(WNT, 1) void conv3_wino_kernel(vae_igemm_args p, const float* __restrict__ U, int tiles_x, int tiles_y) {
+  extern __shared__ __attribute__((aligned(16))) float wsm[];
+  float* const sV = wsm;           // [2][SV]
+  float* const sH = wsm + 2 * SV;  // [2][SHL]: the chunk's input halo, transformed
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const vae_conv_geom g = p.g;
+  const int tilesN = (p.N + WBN - 1) / WBN;
+  int t = blockIdx.x;
+  const int tn = t % tilesN; t /= tilesN;
+  const int tx = t % tiles_x; t /= tiles_x;
+  const int ty = t % tiles_y;
+  const int b = t / tiles_y;
+  const int y0 = ty * WTH, x0 = tx * WTW, n0 = tn * WBN;
+  const int nsteps = p.K / WBK;
+
+  // ---- halo role (threads 0..359): pixel hp of the 10 x 18 input halo, channel quad hq of the chunk.  The chunk's halo is
+  // loaded once (16 bytes per thread), GroupNorm(+SiLU) is applied once per element, and the result goes to sH two steps
+  // ahead of its use; the V role then reads its 4x4 patches from LDS (up to 4 tiles share a pixel) ----
+  const bool hrole = tid < 360;
+  const int hp = tid >> 1, hq = tid & 1;
+  const int hy = y0 - 1 + hp / 18, hx = x0 - 1 + hp % 18;
+  const bool hin = hrole && ((unsigned)hy < (unsigned)g.Hs) && ((unsigned)hx < (unsigned)g.Ws);
+  const auto rsA = VAE_BUF_RSRC(p.A + (int64_t)b * g.Hs * g.Ws * g.Cs, (size_t)g.Hs * g.Ws * g.Cs * 4u);
+  const unsigned hbase = hin ? (unsigned)(((hy * g.Ws + hx) * g.Cs + hq * 4) * 4) : BUF_OOB;
+  f32x4 rhv = {0.f, 0.f, 0.f, 0.f}, rsc = {1.f, 1.f, 1.f, 1.f}, rsh = {0.f, 0.f, 0.f, 0.f};
+  auto load_halo = [&](int step) {
+    const bool ok = hin && step < nsteps;
+    rhv = VAE_BUF_LOAD4(rsA, ok ? hbase + (unsigned)(step * WBK * 4) : BUF_OOB);
+    if (XF != VAE_XF_NONE && ok) {
+      rsc = *reinterpret_cast<const f32x4*>(p.scale + (int64_t)b * g.Cs + step * WBK + hq * 4);
+      rsh = *reinterpret_cast<const f32x4*>(p.shift + (int64_t)b * g.Cs + step * WBK + hq * 4);
+    }
+  };
+  auto store_halo = [&](float* dst) {
+    if (!hrole) return;
+    f32x4 v = rhv;
+    if (XF != VAE_XF_NONE) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float u = v[e] * rsc[e] + rsh[e];
+        if (XF == VAE_XF_AFFINE_SILU) u = silu_f(u);
+        v[e] = hin ? u : 0.f;  // padding stays zero AFTER the transform
+      }
+    }
+    *reinterpret_cast<f32x4*>(&dst[hp * WBK + hq * 4]) = v;
+  };
+
+  // ---- V role (threads 0..255): tile vt, channel vc of the chunk: B^T d B of its 4x4 patch of the staged halo ----
+  const bool vrole = tid < 256;
+  const int vt = (tid >> 3) & 31, vc = tid & 7;
+  const int vorg = ((2 * (vt >> 3)) * 18 + 2 * (vt & 7)) * WBK + vc;  // patch origin in the halo image
+  auto write_v = [&](const float* sHc, float* dst) {
+    if (!vrole) return;
+    float d[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d[i * 4 + j] = sHc[vorg + (i * 18 + j) * WBK];
+    float r[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {  // rows: B^T d
+      r[0 * 4 + j] = d[0 * 4 + j] - d[2 * 4 + j];
+      r[1 * 4 + j] = d[1 * 4 + j] + d[2 * 4 + j];
+      r[2 * 4 + j] = d[2 * 4 + j] - d[1 * 4 + j];
+      r[3 * 4 + j] = d[1 * 4 + j] - d[3 * 4 + j];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {  // columns: (B^T d) B
+      dst[((i * 4 + 0) * NTL + vt) * WBK + vc] = r[i * 4 + 0] - r[i * 4 + 2];
+      dst[((i * 4 + 1) * NTL + vt) * WBK + vc] = r[i * 4 + 1] + r[i * 4 + 2];
+      dst[((i * 4 + 2) * NTL + vt) * WBK + vc] = r[i * 4 + 2] - r[i * 4 + 1];
+      dst[((i * 4 + 3) * NTL + vt) * WBK + vc] = r[i * 4 + 1] - r[i * 4 + 3];
+    }
+  };
+
+  // ---- U fragments: the B operand of position pos, channel block nb is U[step][pos][n0 + 32 nb + lr][4 lh .. 4 lh + 3]: 16
+  // contiguous bytes of the transformed-weight image per lane, 1 KB per wave and (pos, nb).  Only the wave that owns the
+  // position reads them, so they go from global memory (L2) straight into registers, one step ahead, and never touch LDS ----
+  const auto rsU = VAE_BUF_RSRC(U, (size_t)nsteps * 16 * p.N * 8 * 4u);
+  auto load_b = [&](int step, f32x4 (&bq)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int pos = 2 * wave + (i >> 2), n = n0 + (i & 3) * 32 + lr;
+      const bool ok = step < nsteps && n < p.N;
+      bq[i] = VAE_BUF_LOAD4(rsU, ok ? (unsigned)(((((int64_t)step * 16 + pos) * p.N + n) * 8 + lh * 4) * 4) : BUF_OOB);
+    }
+  };
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[pi][nb][e] = 0.f;
+
+  // prologue: halo(0), halo(1) in LDS, V(0) from halo(0); halo(2) and the U fragments of step 0 in registers
+  f32x4 bq0[8], bq1[8];
+  load_b(0, bq0);
+  load_halo(0);
+  store_halo(sH);
+  load_halo(1);
+  store_halo(sH + SHL);
+  load_halo(2);
+  __syncthreads();
+  write_v(sH, sV);
+  __syncthreads();
+  // The two waves of a SIMD (w and w+4) run the step in OPPOSITE order so that one multiplies while the other stages: waves
+  // 0..3 (which own the V transform) stage first and multiply afterwards, waves 4..7 multiply first.  Step s: V(s+1) from
+  // halo(s+1) [published by the previous barrier]; halo(s+2) -> the buffer halo(s) left; requests for the U fragments of step
+  // s+1 (into the register set step s-1 used) and halo(s+3).  One barrier per step: it publishes V(s+1) and halo(s+2).
+  auto multiply = [&](const f32x4* a4, const f32x4 (&bq)[8]) {
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[pi][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[pi][e], bq[pi * 4 + nb][e], acc[pi][nb], 0, 0, 0);
+  };
+  auto stage_next = [&](int s, int par) {
+    if (s + 1 < nsteps) write_v(sH + (par ^ 1) * SHL, sV + (par ^ 1) * SV);  // V(s+1): nobody reads that buffer now
+    store_halo(sH + par * SHL);                                              // halo(s+2)
+    load_halo(s + 3);
+  };
+  auto step = [&](int s, int par, const f32x4 (&cur)[8], f32x4 (&nxt)[8]) {
+    const float* cV = sV + par * SV;
+    f32x4 a4[2];
+    auto read_a = [&]() {
+#pragma unroll
+      for (int pi = 0; pi < 2; ++pi) a4[pi] = *reinterpret_cast<const f32x4*>(&cV[((2 * wave + pi) * NTL + lr) * WBK + 4 * lh]);
+    };
+    load_b(s + 1, nxt);
+    __builtin_amdgcn_sched_barrier(0);
+    if (wave < 4) {  // uniform per wave
+      stage_next(s, par);
+      read_a();
+      __builtin_amdgcn_sched_barrier(0);
+      multiply(a4, cur);
+    } else {
+      read_a();
+      multiply(a4, cur);
+      __builtin_amdgcn_sched_barrier(0);
+      stage_next(s, par);
+    }
+    __syncthreads();
+  };
+  {
+    int s = 0;
+    for (; s + 1 < nsteps; s += 2) {
+      step(s, 0, bq0, bq1);
+      step(s + 1, 1, bq1, bq0);
+    }
+    if (s < nsteps) step(s, 0, bq0, bq1);
+  }
+
+  // ---- epilogue: per 32-channel block, M through LDS, then Y = A^T M A ----
+  float* const sM = wsm;  // [16][32 tiles][SMLD], over the V / halo buffers (the last step's barrier has passed)
+  const size_t obytes = (size_t)g.Ho * g.Wo * p.ldc * 4u;
+  const auto rsC = VAE_BUF_RSRC(p.C + (int64_t)b * g.Ho * g.Wo * p.ldc, obytes);
+  const auto rsR = VAE_BUF_RSRC((p.res ? p.res : p.C) + (int64_t)b * g.Ho * g.Wo * p.ldc, obytes);
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) {
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi) {
+      const int pos = 2 * wave + pi;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int tile = (e & 3) + 8 * (e >> 2) + 4 * lh;
+        sM[(pos * NTL + tile) * SMLD + lr] = acc[pi][nb][e];
+      }
+    }
+    __syncthreads();
+    float gpv = 0.f, gs1 = 0.f, gs2 = 0.f;  // GroupNorm statistics of this thread's 8 outputs of channel `col`: shifted sums
+#pragma unroll
+    for (int rnd = 0; rnd < 2; ++rnd) {
+      const int co = tid & 31, tile = (tid >> 5) + 16 * rnd;
+      float m[16];
+#pragma unroll
+      for (int pos = 0; pos < 16; ++pos) m[pos] = sM[(pos * NTL + tile) * SMLD + co];
+      float h[8];  // A^T M: rows {0: m0+m1+m2, 1: m1-m2-m3} per column
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        h[0 * 4 + j] = (m[0 * 4 + j] + m[1 * 4 + j]) + m[2 * 4 + j];
+        h[1 * 4 + j] = (m[1 * 4 + j] - m[2 * 4 + j]) - m[3 * 4 + j];
+      }
+      const int col = n0 + nb * 32 + co;
+      const float bv = (p.bias && col < p.N) ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const float yv[2] = {(h[a * 4 + 0] + h[a * 4 + 1]) + h[a * 4 + 2], (h[a * 4 + 1] - h[a * 4 + 2]) - h[a * 4 + 3]};
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+          const int oy = y0 + 2 * (tile >> 3) + a, ox = x0 + 2 * (tile & 7) + bb;
+          const unsigned off = (col < p.N && oy < g.Ho && ox < g.Wo) ? (unsigned)(((oy * g.Wo + ox) * p.ldc + col) * 4) : BUF_OOB;
+          float v = yv[bb] + bv;
+          if (p.res) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, off, 0, 0));
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, off, 0, 0);
+          if (rnd == 0 && a == 0 && bb == 0) gpv = v;
+          const float dv = v - gpv;  // (the statistics epilogue only runs on full tiles)
+          gs1 += dv;
+          gs2 += dv * dv;
+        }
+      }
+    }
+    float* const red = sM + 16 * NTL * SMLD;  // [8 waves][groups of the 32-channel block][2]
+    const int cpg = p.gstat ? p.N / p.gstat_groups : 4, ng = 32 / cpg;
+    if (p.gstat) {  // uniform: centred moments of the block's groups; a wave holds 2 tile slots x 32 channels
+      const MeanM2 a = mm2_wave_group(mm2_from_shifted(gpv, gs1, gs2, 8.f), cpg, 8.f);
+      if (lh == 0 && (lr & (cpg - 1)) == 0) {
+        red[(wave * ng + lr / cpg) * 2] = a.m;
+        red[(wave * ng + lr / cpg) * 2 + 1] = a.M2;
+      }
+    }
+    __syncthreads();
+    if (p.gstat && tid < ng) {  // the 8 waves (16 outputs x cpg channels each), fixed order
+      const float nw = 16.f * (float)cpg;
+      MeanM2 a{red[tid * 2], red[tid * 2 + 1]};
+#pragma unroll
+      for (int w = 1; w < 8; ++w) a = mm2_merge(a, nw * (float)w, MeanM2{red[(w * ng + tid) * 2], red[(w * ng + tid) * 2 + 1]}, nw);
+      float* o = p.gstat + (((int64_t)b * (tiles_x * tiles_y) + ty * tiles_x + tx) * p.gstat_groups + (n0 + nb * 32) / cpg + tid) * 2;
+      o[0] = a.m;
+      o[1] = a.M2;
+    }
+  }
+}
+
+}  // namespace
+
+// forward / dgrad of a plain 3x3 stride-1 pad-1 layer in fp32, 8x16-pixel tiles, channel chunks of 8
+bool conv3_wino_eligible(const vae_igemm_args& a) {
+  const vae_conv_geom& g = a.g;
+  if (a.prec != VAE_PREC_F32 || a.A16 != nullptr || a.batch != 1 || a.alpha != 1.0f) return false;
+  if (g.taps != 9 || g.stride != 1 || g.pad_t != 1 || g.pad_l != 1) return false;
+  if (a.tapmask != 0 || a.a_step > 1 || a.c_step > 1 || a.track != nullptr || a.out_bf16) return false;
+  if (!(g.mode == VAE_MODE_FWD || g.mode == VAE_MODE_DGRAD) || g.Ho != g.Hs || g.Wo != g.Ws) return false;
+  if (g.mode == VAE_MODE_DGRAD && a.xf != VAE_XF_NONE) return false;
+  if (g.Ho % WTH != 0 || g.Wo % WTW != 0 || a.K % WBK != 0 || a.K < 64 || a.N < 32 || a.N % 4 != 0 || g.Cs < a.K) return false;
+  if (!aligned16(a.A) || !aligned16(a.C)) return false;
+  if ((size_t)g.Hs * g.Ws * g.Cs * 4u >= BUF_MAX || (size_t)g.Ho * g.Wo * a.ldc * 4u >= BUF_MAX) return false;
+  if ((size_t)a.K * 16 * a.N * 4u >= BUF_MAX) return false;
+  return true;
+}
+
+// chunks per image of the statistics epilogue (0 = not available for these arguments)
+int conv3_wino_gstat_chunks(const vae_igemm_args& a) {
+  const vae_conv_geom& g = a.g;
+  if (a.gstat_groups <= 0 || a.N % WBN != 0 || a.N % a.gstat_groups != 0 || g.mode == VAE_MODE_DGRAD) return 0;
+  const int cpg = a.N / a.gstat_groups;
+  if (cpg != 4 && cpg != 8 && cpg != 16) return 0;
+  return (g.Wo / WTW) * (g.Ho / WTH);
+}
+
+int launch_wino_weights(const vae_igemm_args& a, float* U, hipStream_t st) {
+  const int64_t n = (int64_t)a.N * a.K;
+  hipLaunchKernelGGL(wino_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.W, a.N, a.K, a.g.mode == VAE_MODE_DGRAD ? 1 : 0,
+                     a.sn, a.sk, a.st, U);
+  return 0;
+}
+
+int launch_conv3_wino(const vae_igemm_args& a, const float* U, hipStream_t st) {
+  const vae_conv_geom& g = a.g;
+  const int tx = g.Wo / WTW, ty = g.Ho / WTH;
+  const int64_t nt = (int64_t)((a.N + WBN - 1) / WBN) * tx * ty * g.B;
+  if (nt > 0x7fffffffLL) return VAE_EINVAL;
+  static bool attr_set[3] = {false, false, false};
+  const int xi = a.xf == VAE_XF_NONE ? 0 : (a.xf == VAE_XF_AFFINE ? 1 : 2);
+  const void* fn = xi == 0 ? reinterpret_cast<const void*>(conv3_wino_kernel<VAE_XF_NONE>)
+                 : xi == 1 ? reinterpret_cast<const void*>(conv3_wino_kernel<VAE_XF_AFFINE>)
+                           : reinterpret_cast<const void*>(conv3_wino_kernel<VAE_XF_AFFINE_SILU>);
+  if (!attr_set[xi]) {
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, WINO_LDS) != hipSuccess) {
+      vae_set_error("conv3_wino: cannot reserve %d bytes of LDS", WINO_LDS);
+      return VAE_ELAUNCH;
+    }
+    attr_set[xi] = true;
+  }
+  dim3 grid((unsigned)nt);
+  if (xi == 0) hipLaunchKernelGGL(conv3_wino_kernel<VAE_XF_NONE>, grid, dim3(WNT), WINO_LDS, st, a, U, tx, ty);
+  else if (xi == 1) hipLaunchKernelGGL(conv3_wino_kernel<VAE_XF_AFFINE>, grid, dim3(WNT), WINO_LDS, st, a, U, tx, ty);
+  else hipLaunchKernelGGL(conv3_wino_kernel<VAE_XF_AFFINE_SILU>, grid, dim3(WNT), WINO_LDS, st, a, U, tx, ty);
+  return 0;
+}

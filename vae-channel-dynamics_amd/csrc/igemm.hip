@@ -22,6 +22,10 @@ bool conv3_tile_eligible(const vae_igemm_args& a, bool vec, bool bkm);
 int launch_conv3_tile(const vae_igemm_args& a, bool bkm, hipStream_t st);
 int launch_conv3_tile_bf16(const vae_igemm_args& a, bool bkm, hipStream_t st);
 bool conv3_tile_bf16_packed(const vae_igemm_args& a);
+bool conv3_wino_eligible(const vae_igemm_args& a);                      // conv3_wino.hip (fp32 Winograd F(2x2,3x3))
+int launch_wino_weights(const vae_igemm_args& a, float* U, hipStream_t st);
+int launch_conv3_wino(const vae_igemm_args& a, const float* U, hipStream_t st);
+int conv3_wino_gstat_chunks(const vae_igemm_args& a);
 bool conv3_wide_bf16_eligible(const vae_igemm_args& a);                 // conv3_wide_bf16.hip (both operands bf16 images, 8x32 tiles)
 int conv3_wide_bf16_gstat_chunks(const vae_igemm_args& a);
 int launch_conv3_wide_bf16(const vae_igemm_args& a, hipStream_t st);
@@ -780,6 +784,20 @@ extern "C" int vae_bf16_grad_image_ok(const vae_conv_geom* gp, int32_t Cout, int
 }
 
 static bool rows_is_phase(const vae_igemm_args& a) { return a.tapmask != 0 || a.a_step > 1 || a.c_step > 1; }
+static bool rows_wino(const vae_igemm_args& a) {
+  const bool bkm = rows_bkm(a);
+  return conv3_wino_eligible(a) && rows_vec(a, bkm) && !conv_smallk_eligible(a) && !conv_smalln_eligible(a) && !getenv("VAEHIP_FLAT_CONV") &&
+         !getenv("VAEHIP_NO_WINO");
+}
+extern "C" int vae_wino_ok(const vae_igemm_args* ap) { return (ap && rows_wino(*ap)) ? 1 : 0; }
+extern "C" int64_t vae_wino_weight_floats(const vae_igemm_args* ap) { return ap ? (int64_t)16 * ap->N * ap->K : 0; }
+extern "C" int vae_wino_weights(const vae_igemm_args* ap, float* Wu, void* stream) {
+  VAE_CHECK(ap && Wu && ap->W && aligned16(Wu), "wino_weights: null or unaligned pointer");
+  VAE_CHECK(rows_wino(*ap), "wino_weights: the layer is not served by the Winograd kernel (vae_wino_ok)");
+  if (int rc = launch_wino_weights(*ap, Wu, (hipStream_t)stream)) return rc;
+  VAE_LAUNCH_CHECK("wino_weights");
+  return VAE_OK;
+}
 extern "C" int vae_conv_out_bf16_ok(const vae_igemm_args* ap) {
   if (!ap) return 0;
   const vae_igemm_args& a = *ap;
@@ -799,6 +817,7 @@ extern "C" int vae_conv_phase_ok(const vae_igemm_args* ap) {
 extern "C" int vae_conv_gstat_chunks(const vae_igemm_args* ap) {
   if (!ap) return 0;
   const vae_igemm_args& a = *ap;
+  if (a.Wu != nullptr) return conv3_wino_eligible(a) ? conv3_wino_gstat_chunks(a) : 0;
   const bool bkm = rows_bkm(a), vec = rows_vec(a, bkm);
   if ((a.A16 == nullptr && conv_smallk_eligible(a)) || conv_smalln_eligible(a)) return 0;
   if (rows_use_wide_bf16(a, vec, bkm)) return conv3_wide_bf16_gstat_chunks(a);
@@ -813,7 +832,9 @@ extern "C" int vae_igemm_kernel_name(const vae_igemm_args* ap, char* buf, int32_
   const vae_igemm_args& a = *ap;
   const bool bkm = rows_bkm(a), vec = rows_vec(a, bkm);
   const char* tf[2] = {"false", "true"};
-  if (rows_is_phase(a) && rows_use_wide_bf16(a, vec, bkm))
+  if (a.Wu != nullptr && rows_wino(a))
+    snprintf(buf, n, "conv3_wino_kernel<%d>", a.xf);
+  else if (rows_is_phase(a) && rows_use_wide_bf16(a, vec, bkm))
     snprintf(buf, n, "conv3_wide_bf16_kernel<%s,2>", tf[a.g.mode == VAE_MODE_DGRAD]);
   else if (rows_is_phase(a) && a.prec == VAE_PREC_BF16)
     snprintf(buf, n, "conv3_tile_bf16_kernel<%s,%s,%d,false>", tf[a.g.mode == VAE_MODE_DGRAD], tf[a.g.mode == VAE_MODE_UP2X], a.xf);
@@ -876,6 +897,12 @@ extern "C" int vae_igemm_rows(const vae_igemm_args* ap, void* stream) {
   VAE_CHECK(a.gstat == nullptr || vae_conv_gstat_chunks(ap) > 0, "igemm_rows: no statistics epilogue for these arguments (vae_conv_gstat_chunks)");
   VAE_CHECK(!a.out_bf16 || vae_conv_out_bf16_ok(ap), "igemm_rows: out_bf16 needs a bf16 halo-tile kernel and no bias / res / track / gstat (vae_conv_out_bf16_ok)");
   hipStream_t st = (hipStream_t)stream;
+  if (a.Wu != nullptr) {  // Winograd F(2x2,3x3) with the transformed weights the caller built for THIS geometry
+    VAE_CHECK(rows_wino(a) && aligned16(a.Wu), "igemm_rows: Wu needs a layer vae_wino_ok accepts");
+    if (int rc2 = launch_conv3_wino(a, a.Wu, st)) return rc2;
+    VAE_LAUNCH_CHECK("conv3_wino");
+    return VAE_OK;
+  }
   if (rows_is_phase(a)) {  // sub-sampled views / tap subsets: only the fp32 halo-tile kernel implements them
     VAE_CHECK(vae_conv_phase_ok(ap), "igemm_rows: tapmask / a_step / c_step need a halo-tile kernel (vae_conv_phase_ok)");
     VAE_CHECK(a.track == nullptr && a.gstat == nullptr, "igemm_rows: no tracker / statistics epilogue on a sub-sampled output");

@@ -29,7 +29,7 @@ class IgemmArgs(C.Structure):
                 ("xf", C.c_int32), ("alpha", C.c_float), ("prec", C.c_int32), ("Wh", _fp), ("A16", _fp),
                 ("tapmask", C.c_int32), ("a_step", C.c_int32), ("a_oy", C.c_int32), ("a_ox", C.c_int32),
                 ("c_step", C.c_int32), ("c_oy", C.c_int32), ("c_ox", C.c_int32),
-                ("gstat", _fp), ("gstat_groups", C.c_int32), ("out_bf16", C.c_int32)]
+                ("gstat", _fp), ("gstat_groups", C.c_int32), ("Wu", _fp), ("out_bf16", C.c_int32)]
 
 
 class WgradArgs(C.Structure):
@@ -41,7 +41,7 @@ class WgradArgs(C.Structure):
 
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
-EXPECTED_ABI = 6  # vae_abi_version() of the library these structures and signatures describe
+EXPECTED_ABI = 7  # vae_abi_version() of the library these structures and signatures describe
 
 # name -> argtypes (every function returns int); must list EVERY symbol of include/vaehip.h
 SIGNATURES = {
@@ -49,6 +49,9 @@ SIGNATURES = {
     "vae_conv_gstat_chunks": [C.POINTER(IgemmArgs)],
     "vae_conv_phase_ok": [C.POINTER(IgemmArgs)],
     "vae_conv_out_bf16_ok": [C.POINTER(IgemmArgs)],
+    "vae_wino_ok": [C.POINTER(IgemmArgs)],
+    "vae_wino_weight_floats": [C.POINTER(IgemmArgs)],
+    "vae_wino_weights": [C.POINTER(IgemmArgs), vp, vp],
     "vae_bf16_grad_image_ok": [C.POINTER(ConvGeom), i32, i32],
     "vae_upconv_phase_weights": [vp, i32, i32, vp, vp],
     "vae_wgrad_phase_ok": [C.POINTER(WgradArgs)],
@@ -129,7 +132,7 @@ class _Lib:
                                       f"{dll.vae_sizeof_args(which)} -- lib.py and include/vaehip.h are out of sync")
             for name, argt in SIGNATURES.items():
                 fn = getattr(dll, name)
-                fn.restype = C.c_int
+                fn.restype = C.c_int64 if name == "vae_wino_weight_floats" else C.c_int
                 fn.argtypes = argt
             self._dll = dll
         return self._dll

@@ -212,6 +212,21 @@ def gn_apply_bf16(x: torch.Tensor, st: "Stats", xf: int) -> torch.Tensor:
     return y
 
 
+# fp32 mode: forward and dgrad of the plain 3x3 stride-1 layers as Winograd F(2x2,3x3) (16 instead of 36 multiplications per
+# 2x2 outputs; csrc/conv3_wino.hip).  False = the direct halo-tile kernels (also what VAEHIP_NO_WINO=1 selects in the library)
+WINOGRAD = True
+
+
+def _wino(a: IgemmArgs, dev):
+    """transformed weights for the launch `a` describes when the Winograd kernel serves it (a.Wu is set), else None"""
+    if not WINOGRAD or PRECISION != PREC_F32 or not lib.query("vae_wino_ok", C.byref(a)):
+        return None
+    wu = torch.empty((int(lib.query("vae_wino_weight_floats", C.byref(a))),), device=dev, dtype=torch.float32)
+    lib.call("vae_wino_weights", C.byref(a), _p(wu), _stream())
+    a.Wu = _p(wu)
+    return wu
+
+
 # conv3x3(nearest_upsample_2x(x)) as four phase convolutions on the low-resolution x (2x2 effective kernels: 16 instead
 # of 36 tap-MACs per low-resolution pixel, forward and dgrad); False = the virtual-upsample kernel
 PHASE_UPCONV = True
@@ -374,6 +389,7 @@ def conv_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], kin
     a.xf, a.alpha, a.prec, a.Wh, a.A16 = xf, 1.0, PRECISION, _wh(wv), _p(a16)
     if track is not None:
         assert track.numel() >= ((a.M + 127) // 128) * Co
+    wu = _wino(a, x.device)  # (kept alive until the launch is enqueued; the allocator orders its reuse on the stream)
     if gstat_groups and FUSED_GN_STATS:
         a.gstat_groups = int(gstat_groups)
         nch = lib.query("vae_conv_gstat_chunks", C.byref(a))
@@ -435,6 +451,7 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, kind: str, in_hw: Tuple[int, i
         a.out_bf16 = 1 if o16 else 0
     out = torch.empty((B, Hr, Wr, Ci), device=src.device, dtype=torch.bfloat16 if o16 else torch.float32)
     a.C = _p(out)
+    wu = _wino(a, src.device)
     _launch_igemm(a)
     if kind == "c3up":
         pooled = torch.empty((B, H, W, Ci), device=src.device, dtype=torch.float32)
