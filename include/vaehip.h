@@ -157,6 +157,16 @@ typedef struct vae_wgrad_args {
   int32_t y_step, y_oy, y_ox;
 } vae_wgrad_args;
 int vae_wgrad(const vae_wgrad_args* a, void* stream);
+/* Winograd F(3x3,2x2) weight gradient of plain 3x3 stride-1 layers in fp32 (csrc/wgrad3_wino.hip; 2.25x fewer multiplications
+ * than vae_wgrad).  vae_wgrad_wino_plan: *nsplit = 0 when the layer `a` describes is not served, else the split count to use;
+ * vae_wgrad_wino: a->partial receives the transform-domain slab [nsplit][16][Cin][Cout] (a->out unused), a->bias_partial
+ * (optional) [nsplit][Cout] as in vae_wgrad; vae_wgrad_wino_reduce: fixed-order sum over the splits (into scratch
+ * [16][Cin][Cout], needed when nsplit > 1) + output transform into dW [Cout][3][3][Cin] (OHWI) and, when bias_partial != NULL,
+ * db [Cout].  Replaces the same reference call as vae_wgrad.                                                              */
+int vae_wgrad_wino_plan(const vae_wgrad_args* a, int32_t* nsplit);
+int vae_wgrad_wino(const vae_wgrad_args* a, void* stream);
+int vae_wgrad_wino_reduce(const float* slab, int32_t nsplit, int32_t Cin, int32_t Cout, float* scratch, float* dW,
+                          const float* bias_partial, float* db, void* stream);
 /* 1 when the kernel serving `a` honours tapmask / y_step.. (the fp32 halo-tile wgrad kernel)                       */
 int vae_wgrad_phase_ok(const vae_wgrad_args* a);
 /* transpose of vae_upconv_phase_weights: dWeff [4][Co][3][3][Ci] (+ dbeff [4][Co] or NULL) -> dW [Co][3][3][Ci] (+ db) */

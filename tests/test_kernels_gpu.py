@@ -843,3 +843,52 @@ def test_winograd_forward_and_dgrad(cuda, B, H, W, Ci, Co):
     assert _rel(y0, z0) < 5e-6 and _rel(y1, z1) < 5e-6 and _rel(dx, dz) < 5e-6 and not torch.equal(y0, z0)
     # deterministic
     assert torch.equal(ops.conv_fwd(xd, wd, bias.cuda(), "c3"), y0)
+
+
+# (B,H,W,Ci,Co): several strips per row and rows per image, several images per split, Ci / Co blocks, a single unit row
+WINO_WGRAD_CASES = [(2, 32, 32, 128, 128), (1, 64, 64, 256, 128), (3, 16, 32, 512, 256), (5, 6, 48, 128, 128), (1, 2, 16, 128, 128)]
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co", WINO_WGRAD_CASES)
+def test_winograd_wgrad(cuda, B, H, W, Ci, Co):
+    """F(3x3,2x2) weight gradient (wgrad3_wino.hip) against autograd and against the direct halo-tile kernel, plain and behind
+    GroupNorm+SiLU, with the bias gradient riding along"""
+    from vaehip import ops
+    gen = torch.Generator().manual_seed(43 + Ci + Co + H)
+    x = torch.randn(B, Ci, H, W, generator=gen) * 1.3 + 0.2
+    dy = torch.randn(B, Co, H, W, generator=gen)
+    gamma, beta = 1 + 0.3 * torch.randn(Ci, generator=gen), 0.2 * torch.randn(Ci, generator=gen)
+    xd, dyd = _nhwc(x), _nhwc(dy)
+    st = ops.gn_stats(xd, gamma.cuda(), beta.cuda())
+
+    def run(xf):
+        gw = torch.full((Co, 3, 3, Ci), float("nan"), device="cuda")
+        gb = torch.full((Co,), float("nan"), device="cuda")
+        ops.conv_wgrad(dyd, xd, "c3", gw.permute(0, 3, 1, 2), gb, xf=xf, stats=st if xf else None)
+        return gw, gb
+
+    prof = ops.PROFILER = ops.LaunchProfiler()
+    try:
+        gw0, gb0 = run(ops.XF_NONE)
+        gw1, gb1 = run(ops.XF_AFFINE_SILU)
+    finally:
+        ops.PROFILER = None
+    assert [r[0] for r in prof.records] == ["wgrad3_wino_kernel<0>", "wgrad3_wino_kernel<2>"], [r[0] for r in prof.records]
+    w = torch.zeros(Co, Ci, 3, 3, requires_grad=True)
+    F.conv2d(x, w, torch.zeros(Co), 1, 1).backward(dy)
+    ref0 = w.grad.clone()
+    w.grad = None
+    F.conv2d(F.silu(F.group_norm(x, 32, gamma, beta, 1e-6)), w, None, 1, 1).backward(dy)
+    ref1 = w.grad.clone()
+    refb = dy.sum(dim=(0, 2, 3))
+    assert _rel(gw0.permute(0, 3, 1, 2).cpu(), ref0) < 2e-5 and _rel(gw1.permute(0, 3, 1, 2).cpu(), ref1) < 2e-5
+    assert _rel(gb0.cpu(), refb) < 1e-5 and torch.equal(gb0, gb1)
+    os.environ["VAEHIP_NO_WINO"] = "1"
+    try:
+        dw0, db0 = run(ops.XF_NONE)
+        dw1, _ = run(ops.XF_AFFINE_SILU)
+    finally:
+        del os.environ["VAEHIP_NO_WINO"]
+    assert _rel(gw0, dw0) < 2e-5 and _rel(gw1, dw1) < 2e-5 and _rel(gb0, db0) < 1e-5 and not torch.equal(gw0, dw0)
+    g2, _ = run(ops.XF_NONE)  # deterministic
+    assert torch.equal(g2, gw0)

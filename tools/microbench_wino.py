@@ -1,4 +1,5 @@
-"""fp32 forward / dgrad of the heaviest 3x3 layers: Winograd F(2x2,3x3) vs the direct halo-tile kernels (HIP-event timing).
+"""fp32 forward / dgrad / wgrad of the heaviest 3x3 layers: Winograd F(2x2,3x3) / F(3x3,2x2) vs the direct halo-tile kernels
+(HIP-event timing; the wgrad time includes the split reduction).
 TFLOP/s are ALGORITHMIC (direct-convolution FLOPs / time).  usage: python tools/microbench_wino.py [c128 c256 c512 c512s]"""
 import math
 import os
@@ -32,11 +33,16 @@ for nm in (sys.argv[1:] or list(SHAPES)):
     res = torch.randn((B, H, H, Co), device="cuda", generator=g)
     bias = torch.randn(Co, device="cuda", generator=g)
     w = (torch.randn((Co, 3, 3, Ci), device="cuda", generator=g) / math.sqrt(9 * Ci)).permute(0, 3, 1, 2)
+    gw, gb = torch.empty((Co, 3, 3, Ci), device="cuda").permute(0, 3, 1, 2), torch.empty(Co, device="cuda")
     st = ops.gn_stats(x, torch.ones(Ci, device="cuda"), torch.zeros(Ci, device="cuda"))
     fl = 2.0 * B * H * H * Ci * Co * 9
     runs = {"fwd": lambda: ops.conv_fwd(x, w, None, "c3"),
             "fwd_gnsilu_res": lambda: ops.conv_fwd(x, w, bias, "c3", xf=ops.XF_AFFINE_SILU, stats=st, res=res),
-            "dgrad": lambda: ops.conv_dgrad(dy, w, "c3", (H, H))}
+            "dgrad": lambda: ops.conv_dgrad(dy, w, "c3", (H, H)),
+            "wgrad": lambda: ops.conv_wgrad(dy, x, "c3", gw, gb),
+            "wgrad_gnsilu": lambda: ops.conv_wgrad(dy, x, "c3", gw, gb, xf=ops.XF_AFFINE_SILU, stats=st)}
+    if os.environ.get("MB_ONLY"):
+        runs = {k: v for k, v in runs.items() if k.startswith(os.environ["MB_ONLY"])}
     for variant in ("wino", "direct"):
         if variant == "direct":
             os.environ["VAEHIP_NO_WINO"] = "1"

@@ -33,6 +33,10 @@ int conv3_tile_gstat_chunks(const vae_igemm_args& a);  // both tile kernels shar
 bool wgrad3_tile_eligible(const vae_wgrad_args& a, bool vec);
 int64_t wgrad3_tile_units(const vae_conv_geom& g);
 int launch_wgrad3_tile(const vae_wgrad_args& a, hipStream_t st);
+bool wgrad3_wino_eligible(const vae_wgrad_args& a);
+int64_t wgrad3_wino_units(const vae_conv_geom& g);
+int launch_wgrad3_wino(const vae_wgrad_args& a, hipStream_t st);
+int launch_wino_wgrad_reduce(const float* slab, int nsplit, int N, int M, float* dW, const float* bpart, float* db, hipStream_t st);
 bool wgrad3_tile_bf16_eligible(const vae_wgrad_args& a, bool vec);
 int64_t wgrad3_tile_bf16_units(const vae_conv_geom& g);
 int wgrad3_tile_bf16_columns(const vae_wgrad_args& a);
@@ -958,6 +962,49 @@ extern "C" int vae_igemm_rows(const vae_igemm_args* ap, void* stream) {
   }
   if (rc) return rc;
   VAE_LAUNCH_CHECK("igemm_rows");
+  return VAE_OK;
+}
+
+// Winograd F(3x3,2x2) weight gradient (wgrad3_wino.hip): plan (nsplit = 0: not served), launch into the transform-domain slab
+// [nsplit][16][Cin][Cout] (a->partial; a->bias_partial optional), and the reduction + output transform into OHWI
+extern "C" int vae_wgrad_wino_plan(const vae_wgrad_args* ap, int32_t* nsplit) {
+  VAE_CHECK(ap && nsplit, "wgrad_wino_plan: null argument");
+  *nsplit = 0;
+  if (!wgrad3_wino_eligible(*ap) || getenv("VAEHIP_FLAT_CONV") || getenv("VAEHIP_NO_WINO")) return VAE_OK;
+  const int64_t units = wgrad3_wino_units(ap->g);
+  const int64_t wgs = (int64_t)(ap->M / 128) * (ap->N / 32);
+  *nsplit = (int32_t)std::max<int64_t>(1, std::min<int64_t>(256 / std::max<int64_t>(wgs, 1), units / 8));  // one 8-wave workgroup per CU
+  return VAE_OK;
+}
+extern "C" int vae_wgrad_wino(const vae_wgrad_args* ap, void* stream) {
+  VAE_CHECK(ap != nullptr, "wgrad_wino: null args");
+  const vae_wgrad_args& a = *ap;
+  if (int e = check_geom("wgrad_wino", a.g)) return e;
+  VAE_CHECK(a.dY && a.X && a.partial, "wgrad_wino: null operand");
+  VAE_CHECK(wgrad3_wino_eligible(a), "wgrad_wino: the layer is not served by the Winograd kernel (vae_wgrad_wino_plan)");
+  VAE_CHECK(a.nsplit > 0 && a.nsplit <= 65535, "wgrad_wino: bad nsplit");
+  VAE_CHECK((int64_t)a.g.B * a.g.Ho * a.g.Wo == a.npix && a.N <= a.g.Cs && a.ldy >= a.M, "wgrad_wino: inconsistent sizes");
+  VAE_CHECK(a.xf == VAE_XF_NONE || (a.scale && a.shift), "wgrad_wino: xf needs scale/shift");
+  if (int rc = launch_wgrad3_wino(a, (hipStream_t)stream)) return rc;
+  VAE_LAUNCH_CHECK("wgrad3_wino");
+  return VAE_OK;
+}
+static int reduce_splits_impl(const float* partial, int32_t nsplit, int64_t n, float* out, const float* partial2, int32_t n2, float* out2,
+                              hipStream_t st);
+extern "C" int vae_wgrad_wino_reduce(const float* slab, int32_t nsplit, int32_t Cin, int32_t Cout, float* scratch, float* dW,
+                                     const float* bias_partial, float* db, void* stream) {
+  VAE_CHECK(slab && dW && nsplit > 0 && Cin > 0 && Cout > 0 && Cin % 32 == 0 && Cout % 32 == 0, "wgrad_wino_reduce: bad args");
+  VAE_CHECK((bias_partial == nullptr) == (db == nullptr), "wgrad_wino_reduce: bias_partial and db go together");
+  VAE_CHECK(nsplit == 1 || scratch != nullptr, "wgrad_wino_reduce: nsplit > 1 needs the [16*Cin*Cout] scratch buffer");
+  hipStream_t st = (hipStream_t)stream;
+  if (nsplit > 1) {  // wide fixed-order sum over the splits first (the slab of a 128-channel layer is 64 x 1 MB), then the transform
+    if (int rc = reduce_splits_impl(slab, nsplit, (int64_t)16 * Cin * Cout, scratch, bias_partial, bias_partial ? Cout : 0, db, st)) return rc;
+    VAE_LAUNCH_CHECK("reduce_splits");
+    if (int rc = launch_wino_wgrad_reduce(scratch, 1, Cin, Cout, dW, nullptr, nullptr, st)) return rc;
+  } else {
+    if (int rc = launch_wino_wgrad_reduce(slab, 1, Cin, Cout, dW, bias_partial, db, st)) return rc;
+  }
+  VAE_LAUNCH_CHECK("wino_wgrad_reduce");
   return VAE_OK;
 }
 

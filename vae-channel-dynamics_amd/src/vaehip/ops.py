@@ -517,6 +517,32 @@ def _upconv_phase_wgrad(dy, x, gv, bgrad_out, dy16=None) -> bool:
     return True
 
 
+def _wgrad_wino(a: WgradArgs, gv: torch.Tensor, bgrad_out: Optional[torch.Tensor], dev) -> bool:
+    """fp32 plain 3x3 stride-1 layers: Winograd F(3x3,2x2) weight gradient (csrc/wgrad3_wino.hip) into a transform-domain slab,
+    then the fixed-order reduction + output transform.  False when the layer is not served."""
+    if not WINOGRAD or PRECISION != PREC_F32:
+        return False
+    ns = C.c_int32(0)
+    lib.call("vae_wgrad_wino_plan", C.byref(a), C.byref(ns))
+    ns = ns.value
+    if ns <= 0:
+        return False
+    slab = torch.empty((ns, 16 * a.N * a.M), device=dev, dtype=torch.float32)
+    bpart = torch.empty((ns, a.M), device=dev, dtype=torch.float32) if bgrad_out is not None else None
+    a.nsplit, a.partial, a.bias_partial = ns, _p(slab), _p(bpart)
+    if PROFILER is None:
+        lib.call("vae_wgrad_wino", C.byref(a), _stream())
+    else:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        lib.call("vae_wgrad_wino", C.byref(a), _stream())
+        e1.record()
+        PROFILER.records.append((f"wgrad3_wino_kernel<{a.xf}>", 2.0 * a.M * a.N * a.npix * 9, e0, e1))
+    scratch = torch.empty((16 * a.N * a.M,), device=dev, dtype=torch.float32) if ns > 1 else None
+    lib.call("vae_wgrad_wino_reduce", _p(slab), ns, a.N, a.M, _p(scratch), _p(gv), _p(bpart), _p(bgrad_out), _stream())
+    return True
+
+
 def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, kind: str, wgrad_out: torch.Tensor,
                bgrad_out: Optional[torch.Tensor], *, xf: int = XF_NONE, stats: Optional[Stats] = None,
                x16: Optional[torch.Tensor] = None):
@@ -553,6 +579,8 @@ def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, kind: str, wgrad_out: torch.Te
     if xf != XF_NONE:
         assert stats is not None
         a.scale, a.shift = _p(stats.scale), _p(stats.shift)
+    if _wgrad_wino(a, gv, bgrad_out, x.device):
+        return
     ns, fus = C.c_int32(0), C.c_int32(0)
     lib.call("vae_wgrad_plan", C.byref(a), C.byref(ns), C.byref(fus))
     if xf != XF_NONE and not fus.value:  # tiny spatial size: several batch items per split
