@@ -37,10 +37,27 @@ __global__ __launch_bounds__(GNT, 1) void wgrad3_wino_kernel(vae_wgrad_args p, i
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
   const vae_conv_geom g = p.g;
-  const int tilesN = p.N / GCI;
-  const int tm = blockIdx.x / tilesN, tn = blockIdx.x % tilesN;
+  const int tilesN = p.N / GCI, ntile = tilesN * (p.M / GCO);
+  // Workgroup id -> (tile, split).  Hardware deals consecutive ids round-robin over the 8 XCDs (one L2 each); the tiles of one
+  // split walk through the SAME pixels (every ci block re-reads the dY strip, every co block the X halo), so they are given
+  // ids congruent mod 8: one L2 (or 8 / nsplit of them) fetches a split's rows once.
+  int tile, split;
+  {
+    const int L = blockIdx.x, ns = p.nsplit;
+    if (ns % 8 == 0) {
+      const int j = L >> 3;
+      tile = j % ntile;
+      split = (j / ntile) * 8 + (L & 7);
+    } else if ((ns == 2 || ns == 4) && ntile % (8 / ns) == 0) {
+      split = (L & 7) % ns;
+      tile = (L >> 3) * (8 / ns) + (L & 7) / ns;
+    } else {
+      tile = L % ntile;
+      split = L / ntile;
+    }
+  }
+  const int tm = tile / tilesN, tn = tile % tilesN;
   const int m0 = tm * GCO, n0 = tn * GCI;
-  const int split = blockIdx.y;
   const int64_t per = (nunits + p.nsplit - 1) / p.nsplit;
   const int64_t ubeg = split * per, uend = min(nunits, ubeg + per);
   const int nu = (int)max((int64_t)0, uend - ubeg);
@@ -57,11 +74,23 @@ __global__ __launch_bounds__(GNT, 1) void wgrad3_wino_kernel(vae_wgrad_args p, i
   const int yq = tid >> 4;
   const auto rsX = VAE_BUF_RSRC(p.X, (size_t)g.B * g.Hs * g.Ws * g.Cs * 4u);
   const auto rsY = VAE_BUF_RSRC(p.dY, (size_t)g.B * g.Ho * g.Wo * p.ldy * 4u);
-  f32x4 rx = {0.f, 0.f, 0.f, 0.f}, rxe = rx, ry[2] = {rx, rx}, rsc = {1.f, 1.f, 1.f, 1.f}, rsh = rx, bsum = rx;
-  bool xin = false, xein = false;
+  // Two sets of staging registers: the requests for unit k+2 go out at the start of step k (into the set unit k used) and are
+  // stored during step k+1, so they have a whole step in flight wherever in the step a wave does its stores.
+  struct Stg {
+    f32x4 rx, rxe, ry[2];
+    int b;  // image of the unit (workgroup-uniform)
+    bool xin, xein;
+  };
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  Stg s0{z4, z4, {z4, z4}, -1, false, false}, s1 = s0;
+  f32x4 bsum = z4;
+  // GroupNorm rows of the thread's channel quad for image sc_b: one set, re-read when a stored unit belongs to the next image
+  // (a workgroup's unit range crosses few image boundaries; the re-read waits for L2 once per boundary)
+  f32x4 rsc = {1.f, 1.f, 1.f, 1.f}, rsh = z4;
+  int sc_b = -1;
   // the unit the next load_unit call requests (calls go through ubeg, ubeg+1, ...: counters instead of divisions per step)
   int ub = (int)(ubeg / upi), uty = (int)((ubeg - (int64_t)ub * upi) / strips), ustrip = (int)((ubeg - (int64_t)ub * upi) % strips);
-  auto load_unit = [&](int k) {  // requests for unit ubeg + k (beyond the range: nothing is read, zeros)
+  auto load_unit = [&](int k, Stg& r) {  // requests for unit ubeg + k (beyond the range: nothing is read, zeros)
     const bool ok = k < nu;
     const int b = ub, ty = uty, x0 = ustrip * 16;
     if (++ustrip == strips) {
@@ -72,18 +101,15 @@ __global__ __launch_bounds__(GNT, 1) void wgrad3_wino_kernel(vae_wgrad_args p, i
       }
     }
     const int y = 2 * ty - 1 + xr, x = x0 - 1 + xx;
-    xin = ok && (unsigned)y < (unsigned)g.Hs && (unsigned)x < (unsigned)g.Ws;
-    rx = VAE_BUF_LOAD4(rsX, xin ? (unsigned)(((((int64_t)b * g.Hs + y) * g.Ws + x) * g.Cs + n0 + 4 * xq) * 4) : BUF_OOB);
+    r.xin = ok && (unsigned)y < (unsigned)g.Hs && (unsigned)x < (unsigned)g.Ws;
+    r.rx = VAE_BUF_LOAD4(rsX, r.xin ? (unsigned)(((((int64_t)b * g.Hs + y) * g.Ws + x) * g.Cs + n0 + 4 * xq) * 4) : BUF_OOB);
     const int ye = 2 * ty - 1 + er, xe = x0 - 1 + ex;
-    xein = ok && xe_role && (unsigned)ye < (unsigned)g.Hs && (unsigned)xe < (unsigned)g.Ws;
-    rxe = VAE_BUF_LOAD4(rsX, xein ? (unsigned)(((((int64_t)b * g.Hs + ye) * g.Ws + xe) * g.Cs + n0 + 4 * xq) * 4) : BUF_OOB);
-    if (XF != VAE_XF_NONE && ok) {
-      rsc = *reinterpret_cast<const f32x4*>(p.scale + (int64_t)b * g.Cs + n0 + 4 * xq);
-      rsh = *reinterpret_cast<const f32x4*>(p.shift + (int64_t)b * g.Cs + n0 + 4 * xq);
-    }
+    r.xein = ok && xe_role && (unsigned)ye < (unsigned)g.Hs && (unsigned)xe < (unsigned)g.Ws;
+    r.rxe = VAE_BUF_LOAD4(rsX, r.xein ? (unsigned)(((((int64_t)b * g.Hs + ye) * g.Ws + xe) * g.Cs + n0 + 4 * xq) * 4) : BUF_OOB);
+    r.b = ok ? b : -1;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
-      ry[a] = VAE_BUF_LOAD4(rsY, ok ? (unsigned)(((((int64_t)b * g.Ho + 2 * ty + a) * g.Wo + x0 + xx) * p.ldy + m0 + 4 * yq) * 4) : BUF_OOB);
+      r.ry[a] = VAE_BUF_LOAD4(rsY, ok ? (unsigned)(((((int64_t)b * g.Ho + 2 * ty + a) * g.Wo + x0 + xx) * p.ldy + m0 + 4 * yq) * 4) : BUF_OOB);
   };
   auto xform = [&](f32x4 v, bool in) {
     if (XF != VAE_XF_NONE) {
@@ -96,22 +122,27 @@ __global__ __launch_bounds__(GNT, 1) void wgrad3_wino_kernel(vae_wgrad_args p, i
     }
     return v;
   };
-  auto store_unit = [&](float* st) {
+  auto store_unit = [&](float* st, const Stg& r) {
     float* sx = st;
     float* sy = st + SXF;
-    const f32x4 v = xform(rx, xin);
+    if (XF != VAE_XF_NONE && r.b >= 0 && r.b != sc_b) {  // workgroup-uniform
+      sc_b = r.b;
+      rsc = *reinterpret_cast<const f32x4*>(p.scale + (int64_t)sc_b * g.Cs + n0 + 4 * xq);
+      rsh = *reinterpret_cast<const f32x4*>(p.shift + (int64_t)sc_b * g.Cs + n0 + 4 * xq);
+    }
+    const f32x4 v = xform(r.rx, r.xin);
 #pragma unroll
     for (int e = 0; e < 4; ++e) sx[(xr * GCI + 4 * xq + e) * XS + xx] = v[e];
     if (xe_role) {
-      const f32x4 ve = xform(rxe, xein);
+      const f32x4 ve = xform(r.rxe, r.xein);
 #pragma unroll
       for (int e = 0; e < 4; ++e) sx[(er * GCI + 4 * xq + e) * XS + ex] = ve[e];
     }
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) sy[(a * GCO + 4 * yq + e) * XS + xx] = ry[a][e];
-      if (do_bias) bsum += ry[a];
+      for (int e = 0; e < 4; ++e) sy[(a * GCO + 4 * yq + e) * XS + xx] = r.ry[a][e];
+      if (do_bias) bsum += r.ry[a];
     }
   };
 
@@ -119,12 +150,9 @@ __global__ __launch_bounds__(GNT, 1) void wgrad3_wino_kernel(vae_wgrad_args p, i
   const int wi = wave >> 1, jh = wave & 1;
   // V row combination: B^T row i = x[r1] + sg * x[r2]
   const int vr1 = wi == 0 ? 0 : (wi == 2 ? 2 : 1), vr2 = wi == 0 ? 2 : (wi == 1 ? 2 : (wi == 2 ? 1 : 3));
-  const float vsg = wi == 1 ? 1.f : -1.f;
   const int voff1 = (vr1 * GCI + lr) * XS + 8 * lh, voff2 = (vr2 * GCI + lr) * XS + 8 * lh;
   // D' row combination: i = 0: dy row 0, 3: row 1, 1: row0 + row1, 2: row0 - row1
-  const bool dtwo = wi == 1 || wi == 2;
   const int dr1 = wi == 3 ? 1 : 0;
-  const float dsg = wi == 1 ? 1.f : -1.f;
 
   f32x16 acc[2][4];
 #pragma unroll
@@ -134,21 +162,26 @@ __global__ __launch_bounds__(GNT, 1) void wgrad3_wino_kernel(vae_wgrad_args p, i
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[pi][nb][e] = 0.f;
 
-  load_unit(0);
-  store_unit(smem);
-  load_unit(1);
+  load_unit(0, s0);
+  store_unit(smem, s0);
+  load_unit(1, s1);
   __syncthreads();
 
   // The loop body is instantiated per (two-row D combination?, column pair): straight-line code, no per-step branches.
-  auto run = [&](auto DT, auto JH) {
-    constexpr bool two = decltype(DT)::value;
-    constexpr int jhc = decltype(JH)::value;
-    for (int k = 0; k < nu; ++k) {
+  auto run = [&](auto WI, auto JH) {
+    constexpr int wic = decltype(WI)::value, jhc = decltype(JH)::value;
+    constexpr bool two = wic == 1 || wic == 2;  // D' row i combines both dY rows
+    constexpr bool vplus = wic == 1;            // sign of the second row in the combinations (V: B^T row i, D': G' row i)
+    auto step = [&](int k, const Stg& cur, Stg& nxt) {  // cur: unit k+1 (requested during step k-1); nxt receives unit k+2
+      load_unit(k + 2, nxt);
       const float* cx = smem + (k & 1) * GSTAGE;
       const float* cy = cx + SXF;
       float* nst = smem + ((k + 1) & 1) * GSTAGE;
-      // raw dY rows of channel block 0 (requested first: they are needed right after the V fragments)
-      f32x4 rd[2][2][2];  // [set][row][x quad]
+      // D' operands: raw dY rows of channel block nb -> b4 of the two positions.  The operands of block nb+1 are formed and
+      // the rows of block nb+2 requested WHILE the MFMAs of block nb issue (interleaved below): the two waves of a SIMD
+      // take turns on the matrix pipe and so drift into the same phase -- operand building in a phase of its own would leave
+      // the pipe idle in both at once.
+      f32x4 rd[2][2];  // [row][x quad]
       auto read_d = [&](int nb, f32x4 (&d)[2][2]) {
         const int doff = (dr1 * GCO + nb * 32 + lr) * XS + 8 * lh;
 #pragma unroll
@@ -157,41 +190,12 @@ __global__ __launch_bounds__(GNT, 1) void wgrad3_wino_kernel(vae_wgrad_args p, i
           if (two) d[1][c] = *reinterpret_cast<const f32x4*>(&cy[doff + GCO * XS + 4 * c]);
         }
       };
-      // V fragments of the two positions: 12 x values of the two rows, combined
-      f32x4 a4[2];
-      {
-        f32x4 u1[3], u2[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          u1[c] = *reinterpret_cast<const f32x4*>(&cx[voff1 + 4 * c]);
-          u2[c] = *reinterpret_cast<const f32x4*>(&cx[voff2 + 4 * c]);
-        }
-        read_d(0, rd[0]);
-        float rc[12];
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) rc[4 * c + e] = u1[c][e] + vsg * u2[c][e];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (jhc == 0) {
-            a4[0][e] = rc[2 * e] - rc[2 * e + 2];
-            a4[1][e] = rc[2 * e + 1] + rc[2 * e + 2];
-          } else {
-            a4[0][e] = rc[2 * e + 2] - rc[2 * e + 1];
-            a4[1][e] = rc[2 * e + 1] - rc[2 * e + 3];
-          }
-        }
-      }
-#pragma unroll
-      for (int nb = 0; nb < 4; ++nb) {
-        const f32x4 (&d)[2][2] = rd[nb & 1];
+      auto build_b = [&](const f32x4 (&d)[2][2], f32x4 (&b4)[2]) {
         float rc[8];
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) rc[4 * c + e] = two ? d[0][c][e] + dsg * d[1][c][e] : d[0][c][e];
-        f32x4 b4[2];
+          for (int e = 0; e < 4; ++e) rc[4 * c + e] = !two ? d[0][c][e] : (vplus ? d[0][c][e] + d[1][c][e] : d[0][c][e] - d[1][c][e]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           if (jhc == 0) {
@@ -202,29 +206,77 @@ __global__ __launch_bounds__(GNT, 1) void wgrad3_wino_kernel(vae_wgrad_args p, i
             b4[1][e] = rc[2 * e + 1];
           }
         }
+      };
+      // V fragments of the two positions: 12 x values of the two rows, combined
+      f32x4 a4[2], bb[2][2];
+      {
+        f32x4 u1[3], u2[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          u1[c] = *reinterpret_cast<const f32x4*>(&cx[voff1 + 4 * c]);
+          u2[c] = *reinterpret_cast<const f32x4*>(&cx[voff2 + 4 * c]);
+        }
+        float rc[12];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) rc[4 * c + e] = vplus ? u1[c][e] + u2[c][e] : u1[c][e] - u2[c][e];
         __builtin_amdgcn_sched_barrier(0);
-        if (nb < 3) read_d(nb + 1, rd[(nb + 1) & 1]);  // in flight during this block's MFMAs
+        read_d(0, rd);  // (after the row combination: its 24 input registers are free again)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (jhc == 0) {
+            a4[0][e] = rc[2 * e] - rc[2 * e + 2];
+            a4[1][e] = rc[2 * e + 1] + rc[2 * e + 2];
+          } else {
+            a4[0][e] = rc[2 * e + 2] - rc[2 * e + 1];
+            a4[1][e] = rc[2 * e + 1] - rc[2 * e + 3];
+          }
+        }
+        build_b(rd, bb[0]);
+        read_d(1, rd);
+      }
+      if (wave < 4) store_unit(nst, cur);  // the two waves of a SIMD store at opposite ends of the step
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
         __builtin_amdgcn_sched_barrier(0);
+        if (nb < 3) build_b(rd, bb[(nb + 1) & 1]);  // block nb+1's operands, during the first half of this block's MFMAs
+        if (nb < 2) read_d(nb + 2, rd);             // block nb+2's rows into the same registers, during the second half
 #pragma unroll
         for (int pi = 0; pi < 2; ++pi)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[pi][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[pi][e], b4[pi][e], acc[pi][nb], 0, 0, 0);
+          for (int e = 0; e < 4; ++e) acc[pi][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[pi][e], bb[nb & 1][pi][e], acc[pi][nb], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);  // VALU
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);  // DS read
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
-      store_unit(nst);   // unit k+1, requested a whole step ago
-      load_unit(k + 2);
+      if (wave >= 4) store_unit(nst, cur);
       __syncthreads();
+    };
+    int k = 0;
+    for (; k + 1 < nu; k += 2) {
+      step(k, s1, s0);
+      step(k + 1, s0, s1);
     }
+    if (k < nu) step(k, s1, s0);
   };
   {
-    using T = std::true_type;
-    using F = std::false_type;
-    if (dtwo) {
-      if (jh) run(T{}, std::integral_constant<int, 1>{});
-      else run(T{}, std::integral_constant<int, 0>{});
-    } else {
-      if (jh) run(F{}, std::integral_constant<int, 1>{});
-      else run(F{}, std::integral_constant<int, 0>{});
+    using J0 = std::integral_constant<int, 0>;
+    using J1 = std::integral_constant<int, 1>;
+    switch (wave) {  // (wave-uniform: wi = wave / 2, jh = wave % 2)
+      case 0: run(std::integral_constant<int, 0>{}, J0{}); break;
+      case 1: run(std::integral_constant<int, 0>{}, J1{}); break;
+      case 2: run(std::integral_constant<int, 1>{}, J0{}); break;
+      case 3: run(std::integral_constant<int, 1>{}, J1{}); break;
+      case 4: run(std::integral_constant<int, 2>{}, J0{}); break;
+      case 5: run(std::integral_constant<int, 2>{}, J1{}); break;
+      case 6: run(std::integral_constant<int, 3>{}, J0{}); break;
+      default: run(std::integral_constant<int, 3>{}, J1{}); break;
     }
   }
 
@@ -324,7 +376,7 @@ int64_t wgrad3_wino_units(const vae_conv_geom& g) { return (int64_t)g.B * (g.Ho 
 int launch_wgrad3_wino(const vae_wgrad_args& a, hipStream_t st) {
   const vae_conv_geom& g = a.g;
   const int64_t nunits = wgrad3_wino_units(g);
-  dim3 grid((unsigned)((a.M / GCO) * (a.N / GCI)), (unsigned)a.nsplit, 1);
+  dim3 grid((unsigned)((a.M / GCO) * (a.N / GCI) * a.nsplit), 1, 1);
   const int strips = g.Wo / 16;
   if (a.xf == VAE_XF_NONE) hipLaunchKernelGGL(wgrad3_wino_kernel<VAE_XF_NONE>, grid, dim3(GNT), 0, st, a, strips, nunits);
   else if (a.xf == VAE_XF_AFFINE) hipLaunchKernelGGL(wgrad3_wino_kernel<VAE_XF_AFFINE>, grid, dim3(GNT), 0, st, a, strips, nunits);
