@@ -261,6 +261,11 @@ def main():
                     "avg_launch_ms": round(dom[1]["ms"] / dom[1]["launches"], 4),
                     "all_contraction_kernels_tflops": round(allk, 2),
                     "contraction_ms_per_step": round(tot_ms / args.steps, 2)}
+            if "wino" in dom[0]:  # Winograd: 16 multiplications per 36 algorithmic MACs -- the MFMA work actually issued
+                roof["mfma_executed"] = round(ach * 16.0 / 36.0, 2)
+                roof["mfma_executed_frac"] = round(ach * 16.0 / 36.0 / peak, 4)
+                roof["note"] = ("achieved / frac count the ALGORITHMIC (direct-convolution) FLOPs of the layer, so a Winograd kernel can exceed "
+                                "the MFMA peak; mfma_executed is the matrix work it issues (16/36 of that) against the same peak")
         hbm = None  # step-level HBM rate (north_star: achieved HBM GB/s vs the 8 TB/s roofline), bytes from the committed PMC passes
         try:
             tfile = "r02_hbm_traffic.json" if args.dtype == "f32" else "r02_hbm_traffic_bf16.json"

@@ -90,6 +90,13 @@ __global__ __launch_bounds__(GNT, 1) void wgrad3_wino_kernel(vae_wgrad_args p, i
   int sc_b = -1;
   // the unit the next load_unit call requests (calls go through ubeg, ubeg+1, ...: counters instead of divisions per step)
   int ub = (int)(ubeg / upi), uty = (int)((ubeg - (int64_t)ub * upi) / strips), ustrip = (int)((ubeg - (int64_t)ub * upi) % strips);
+  // Addresses = a workgroup-uniform part (scalar registers) + a per-thread constant; an element is padding when one of the
+  // thread's position flags meets the unit's border flag (bit 0: first halo row / top border, 1: last halo row / bottom border,
+  // 2: first halo column / left border, 3: last halo column / right border, 4: always / unit beyond the range).
+  const unsigned thrX = ((xr * g.Ws + xx) * g.Cs + n0 + 4 * xq) * 4u, thrE = ((er * g.Ws + ex) * g.Cs + n0 + 4 * xq) * 4u;
+  const unsigned thrY = (xx * p.ldy + m0 + 4 * yq) * 4u, rowY = (unsigned)g.Wo * p.ldy * 4u;
+  const int tfX = (xr == 0 ? 1 : 0) | (xr == 3 ? 2 : 0) | (xx == 0 ? 4 : 0) | 16;
+  const int tfE = xe_role ? ((er == 0 ? 1 : 0) | (er == 3 ? 2 : 0) | (ex == 17 ? 8 : 0) | 16) : 31;
   auto load_unit = [&](int k, Stg& r) {  // requests for unit ubeg + k (beyond the range: nothing is read, zeros)
     const bool ok = k < nu;
     const int b = ub, ty = uty, x0 = ustrip * 16;
@@ -100,16 +107,17 @@ __global__ __launch_bounds__(GNT, 1) void wgrad3_wino_kernel(vae_wgrad_args p, i
         ++ub;
       }
     }
-    const int y = 2 * ty - 1 + xr, x = x0 - 1 + xx;
-    r.xin = ok && (unsigned)y < (unsigned)g.Hs && (unsigned)x < (unsigned)g.Ws;
-    r.rx = VAE_BUF_LOAD4(rsX, r.xin ? (unsigned)(((((int64_t)b * g.Hs + y) * g.Ws + x) * g.Cs + n0 + 4 * xq) * 4) : BUF_OOB);
-    const int ye = 2 * ty - 1 + er, xe = x0 - 1 + ex;
-    r.xein = ok && xe_role && (unsigned)ye < (unsigned)g.Hs && (unsigned)xe < (unsigned)g.Ws;
-    r.rxe = VAE_BUF_LOAD4(rsX, r.xein ? (unsigned)(((((int64_t)b * g.Hs + ye) * g.Ws + xe) * g.Cs + n0 + 4 * xq) * 4) : BUF_OOB);
     r.b = ok ? b : -1;
+    const int uf = (ty == 0 ? 1 : 0) | (2 * ty + 2 >= g.Hs ? 2 : 0) | (x0 == 0 ? 4 : 0) | (x0 + 16 >= g.Ws ? 8 : 0) | (ok ? 0 : 16);
+    // (the halo origin may lie before the tensor: unsigned arithmetic wraps, the sum with the thread's part is exact)
+    const unsigned baseX = (unsigned)((b * g.Hs + 2 * ty - 1) * g.Ws + x0 - 1) * (unsigned)g.Cs * 4u;
+    const unsigned baseY = (unsigned)((b * g.Ho + 2 * ty) * g.Wo + x0) * (unsigned)p.ldy * 4u;
+    r.xin = (tfX & uf) == 0;
+    r.rx = VAE_BUF_LOAD4(rsX, r.xin ? baseX + thrX : BUF_OOB);
+    r.xein = (tfE & uf) == 0;
+    r.rxe = VAE_BUF_LOAD4(rsX, r.xein ? baseX + thrE : BUF_OOB);
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
-      r.ry[a] = VAE_BUF_LOAD4(rsY, ok ? (unsigned)(((((int64_t)b * g.Ho + 2 * ty + a) * g.Wo + x0 + xx) * p.ldy + m0 + 4 * yq) * 4) : BUF_OOB);
+    for (int a = 0; a < 2; ++a) r.ry[a] = VAE_BUF_LOAD4(rsY, ok ? baseY + a * rowY + thrY : BUF_OOB);
   };
   auto xform = [&](f32x4 v, bool in) {
     if (XF != VAE_XF_NONE) {
