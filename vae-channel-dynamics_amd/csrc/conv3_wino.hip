@@ -157,13 +157,18 @@ __global__ __launch_bounds__(WNT, 1) void conv3_wino_kernel(vae_igemm_args p, co
   // contiguous bytes of the transformed-weight image per lane, 1 KB per wave and (pos, nb).  Only the wave that owns the
   // position reads them, so they go from global memory (L2) straight into registers, one step ahead, and never touch LDS ----
   const auto rsU = VAE_BUF_RSRC(U, (size_t)nsteps * 16 * p.N * 8 * 4u);
-  auto load_b = [&](int step, f32x4 (&bq)[8]) {
+  // address = per-thread constant (one per channel block; out of range for channels beyond N) + a workgroup-uniform part in
+  // a scalar register: one instruction per load
+  unsigned bvo[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int pos = 2 * wave + (i >> 2), n = n0 + (i & 3) * 32 + lr;
-      const bool ok = step < nsteps && n < p.N;
-      bq[i] = VAE_BUF_LOAD4(rsU, ok ? (unsigned)(((((int64_t)step * 16 + pos) * p.N + n) * 8 + lh * 4) * 4) : BUF_OOB);
-    }
+  for (int q = 0; q < 4; ++q) bvo[q] = (n0 + q * 32 + lr < p.N) ? (unsigned)(((n0 + q * 32 + lr) * 8 + lh * 4) * 4) : BUF_OOB;
+  const unsigned bpos = (unsigned)p.N * 32u;  // bytes per position of the U image
+  auto load_b = [&](int step, f32x4 (&bq)[8]) {
+    if (step >= nsteps) return;  // (uniform; the registers are not used again)
+    const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(step * 16 + 2 * wave) * bpos);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      bq[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsU, bvo[i & 3], so + (i >> 2) * bpos, 0));
   };
 
   f32x16 acc[2][4];
@@ -238,8 +243,24 @@ __global__ __launch_bounds__(WNT, 1) void conv3_wino_kernel(vae_igemm_args p, co
   const size_t obytes = (size_t)g.Ho * g.Wo * p.ldc * 4u;
   const auto rsC = VAE_BUF_RSRC(p.C + (int64_t)b * g.Ho * g.Wo * p.ldc, obytes);
   const auto rsR = VAE_BUF_RSRC((p.res ? p.res : p.C) + (int64_t)b * g.Ho * g.Wo * p.ldc, obytes);
+  // byte offsets of this thread's 8 outputs per channel block (2 tile slots x 2 x 2 pixels, channel n0 + (tid & 31))
+  unsigned offp[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int tile = (tid >> 5) + 16 * (q >> 2), oy = y0 + 2 * (tile >> 3) + ((q >> 1) & 1), ox = x0 + 2 * (tile & 7) + (q & 1);
+    offp[q] = (oy < g.Ho && ox < g.Wo) ? (unsigned)(((oy * g.Wo + ox) * p.ldc + n0 + (tid & 31)) * 4) : BUF_OOB;
+  }
 #pragma unroll
   for (int nb = 0; nb < 4; ++nb) {
+    // the residual values of the block are requested before the LDS round trip below, not one by one in front of each store
+    const bool cok = n0 + nb * 32 + (tid & 31) < p.N;
+    unsigned off[8];
+    float rres[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      off[q] = (cok && offp[q] != BUF_OOB) ? offp[q] + nb * 128u : BUF_OOB;
+      rres[q] = p.res ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, off[q], 0, 0)) : 0.f;
+    }
 #pragma unroll
     for (int pi = 0; pi < 2; ++pi) {
       const int pos = 2 * wave + pi;
@@ -270,11 +291,10 @@ __global__ __launch_bounds__(WNT, 1) void conv3_wino_kernel(vae_igemm_args p, co
         const float yv[2] = {(h[a * 4 + 0] + h[a * 4 + 1]) + h[a * 4 + 2], (h[a * 4 + 1] - h[a * 4 + 2]) - h[a * 4 + 3]};
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb) {
-          const int oy = y0 + 2 * (tile >> 3) + a, ox = x0 + 2 * (tile & 7) + bb;
-          const unsigned off = (col < p.N && oy < g.Ho && ox < g.Wo) ? (unsigned)(((oy * g.Wo + ox) * p.ldc + col) * 4) : BUF_OOB;
+          const int q = rnd * 4 + a * 2 + bb;
           float v = yv[bb] + bv;
-          if (p.res) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, off, 0, 0));
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, off, 0, 0);
+          if (p.res) v += rres[q];
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, off[q], 0, 0);
           if (rnd == 0 && a == 0 && bb == 0) gpv = v;
           const float dv = v - gpv;  // (the statistics epilogue only runs on full tiles)
           gs1 += dv;
