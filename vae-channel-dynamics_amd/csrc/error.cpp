@@ -13,7 +13,7 @@ void vae_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* vae_last_error(void) { return g_err; }
-extern "C" int vae_abi_version(void) { return 7; }
+extern "C" int vae_abi_version(void) { return 8; }
 extern "C" int vae_sizeof_args(int32_t which) {
   return which == 0 ? (int)sizeof(vae_conv_geom) : which == 1 ? (int)sizeof(vae_igemm_args) : which == 2 ? (int)sizeof(vae_wgrad_args) : -1;
 }
