@@ -102,28 +102,33 @@ __global__ __launch_bounds__(WNT, 1) void conv3_wino_kernel(vae_igemm_args p, co
   const bool hin = hrole && ((unsigned)hy < (unsigned)g.Hs) && ((unsigned)hx < (unsigned)g.Ws);
   const auto rsA = VAE_BUF_RSRC(p.A + (int64_t)b * g.Hs * g.Ws * g.Cs, (size_t)g.Hs * g.Ws * g.Cs * 4u);
   const unsigned hbase = hin ? (unsigned)(((hy * g.Ws + hx) * g.Cs + hq * 4) * 4) : BUF_OOB;
-  f32x4 rhv = {0.f, 0.f, 0.f, 0.f}, rsc = {1.f, 1.f, 1.f, 1.f}, rsh = {0.f, 0.f, 0.f, 0.f};
-  auto load_halo = [&](int step) {
+  struct Halo {
+    f32x4 v, sc, sh;
+  };
+  Halo rh{{0.f, 0.f, 0.f, 0.f}, {1.f, 1.f, 1.f, 1.f}, {0.f, 0.f, 0.f, 0.f}};
+  auto load_halo_into = [&](int step, Halo& h) {
     const bool ok = hin && step < nsteps;
-    rhv = VAE_BUF_LOAD4(rsA, ok ? hbase + (unsigned)(step * WBK * 4) : BUF_OOB);
+    h.v = VAE_BUF_LOAD4(rsA, ok ? hbase + (unsigned)(step * WBK * 4) : BUF_OOB);
     if (XF != VAE_XF_NONE && ok) {
-      rsc = *reinterpret_cast<const f32x4*>(p.scale + (int64_t)b * g.Cs + step * WBK + hq * 4);
-      rsh = *reinterpret_cast<const f32x4*>(p.shift + (int64_t)b * g.Cs + step * WBK + hq * 4);
+      h.sc = *reinterpret_cast<const f32x4*>(p.scale + (int64_t)b * g.Cs + step * WBK + hq * 4);
+      h.sh = *reinterpret_cast<const f32x4*>(p.shift + (int64_t)b * g.Cs + step * WBK + hq * 4);
     }
   };
-  auto store_halo = [&](float* dst) {
+  auto store_halo_from = [&](float* dst, const Halo& h) {
     if (!hrole) return;
-    f32x4 v = rhv;
+    f32x4 v = h.v;
     if (XF != VAE_XF_NONE) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float u = v[e] * rsc[e] + rsh[e];
+        float u = v[e] * h.sc[e] + h.sh[e];
         if (XF == VAE_XF_AFFINE_SILU) u = silu_f(u);
         v[e] = hin ? u : 0.f;  // padding stays zero AFTER the transform
       }
     }
     *reinterpret_cast<f32x4*>(&dst[hp * WBK + hq * 4]) = v;
   };
+  auto load_halo = [&](int step) { load_halo_into(step, rh); };
+  auto store_halo = [&](float* dst) { store_halo_from(dst, rh); };
 
   // ---- V role (threads 0..255): tile vt, channel vc of the chunk: B^T d B of its 4x4 patch of the staged halo ----
   const bool vrole = tid < 256;
@@ -182,11 +187,14 @@ __global__ __launch_bounds__(WNT, 1) void conv3_wino_kernel(vae_igemm_args p, co
   // prologue: halo(0), halo(1) in LDS, V(0) from halo(0); halo(2) and the U fragments of step 0 in registers
   f32x4 bq0[8], bq1[8];
   load_b(0, bq0);
-  load_halo(0);
-  store_halo(sH);
-  load_halo(1);
-  store_halo(sH + SHL);
-  load_halo(2);
+  {  // the three halo requests of the prologue go out together (one memory latency, not two)
+    Halo h0 = rh, h1 = rh;
+    load_halo_into(0, h0);
+    load_halo_into(1, h1);
+    load_halo(2);
+    store_halo_from(sH, h0);
+    store_halo_from(sH + SHL, h1);
+  }
   __syncthreads();
   write_v(sH, sV);
   __syncthreads();
