@@ -802,8 +802,12 @@ def test_groupnorm_statistics_with_large_mean(cuda, ratio):
 WINO_CASES = [(2, 32, 32, 128, 128), (1, 64, 64, 256, 128), (2, 16, 32, 512, 512), (6, 16, 48, 128, 160), (2, 8, 16, 128, 32)]
 
 
+@pytest.mark.parametrize("nb4", [False, True])
 @pytest.mark.parametrize("B,H,W,Ci,Co", WINO_CASES)
-def test_winograd_forward_and_dgrad(cuda, B, H, W, Ci, Co):
+def test_winograd_forward_and_dgrad(cuda, monkeypatch, B, H, W, Ci, Co, nb4):
+    """default: 64 output channels per workgroup, two workgroups per CU; VAEHIP_WINO_NB4: 128 channels, one per CU"""
+    if nb4:
+        monkeypatch.setenv("VAEHIP_WINO_NB4", "1")
     from vaehip import ops
     gen = torch.Generator().manual_seed(41 + Ci + Co + H)
     x = torch.randn(B, Ci, H, W, generator=gen) * 1.3 + 0.2

@@ -7,12 +7,14 @@
 //   * U = G g G^T is built once per launch by vae_wino_weights from the LIVE weights (they change every optimizer step and
 //     the nudger edits parameters in place), laid out [K/8][16][N][8]: a workgroup's slab of one channel chunk is 16
 //     contiguous 4 KB pieces.  For dgrad the kernel is rotated and transposed there (N = Cin, K = Cout).
-//   * Workgroup (8 waves) = 8 x 16 output pixels (32 Winograd tiles) x 128 output channels; channel chunk of 8 per step.
+//   * Workgroup (8 waves) = 8 x 16 output pixels (32 Winograd tiles) x 64 output channels (NB = 2 channel blocks), channel
+//     chunk of 8 per step; 64 accumulator registers per wave, 128 VGPRs, so TWO workgroups share a CU and fill each other's
+//     barrier / load bubbles (NB = 4: 128 channels, 256 VGPRs, one workgroup per CU, was 4-10 % slower; VAEHIP_WINO_NB4=1).
 //     Threads 0..359 load the chunk's 10 x 18 input halo once (GroupNorm + SiLU applied once per element) into LDS two steps
 //     ahead; threads 0..255 each own one (tile, channel) of the chunk, take B^T d B of the 4x4 patch (32 additions) and write
 //     the 16 values into the V image [16][32][8] (double buffered).  Wave w multiplies positions 2w, 2w+1: per position ONE
-//     16-byte A fragment row read covers the chunk (k = 4*half + s over 4 MFMAs) against 4 B fragments (channel blocks):
-//     32 MFMAs per wave and step.
+//     16-byte A fragment row read covers the chunk (k = 4*half + s over 4 MFMAs) against NB B fragments (channel blocks):
+//     8 NB MFMAs per wave and step.  The GroupNorm scale / shift rows of the image sit in LDS (read when a halo is stored).
 //   * The B fragment of (position, channel block) is 16 contiguous bytes per lane of the U image, and only the wave that owns
 //     the position needs it: U goes from L2 straight into registers, one step ahead (two register sets), never through LDS.
 //     One barrier per step (it publishes the next V); the two waves of a SIMD run the step in opposite order (stage then
@@ -31,13 +33,14 @@ namespace {
 constexpr int WTH = 8, WTW = 16;          // output pixels per workgroup tile
 constexpr int NTL = 32;                   // Winograd tiles per workgroup (4 rows x 8 columns of 2x2 outputs)
 constexpr int WBK = 8;                    // channels per step
-constexpr int WBN = 128, WNT = 512;
+constexpr int WNT = 512;
 constexpr int SV = 16 * NTL * WBK;        // floats per V buffer (16384 B): rows of 8 floats, a wave's 16-byte fragment reads
                                           // cover 1 KB contiguously and the transform's 4-byte writes are thread-contiguous
 constexpr int SMLD = 33;                  // epilogue image row (floats)
 constexpr int SHL = 180 * WBK;            // floats per halo buffer (10 x 18 pixels x 8 channels, 5760 B)
 constexpr int SM = 16 * NTL * SMLD + 8 * 8 * 2;  // epilogue image + statistics scratch; overlays the V / halo buffers
-constexpr int WINO_LDS = (SM > 2 * SV + 2 * SHL ? SM : 2 * SV + 2 * SHL) * 4;  // 68096 B
+constexpr int WSS = 2 * 1024;             // GroupNorm scale / shift rows of the image (K <= 1024)
+constexpr int WINO_LDS = (SM > 2 * SV + 2 * SHL + WSS ? SM : 2 * SV + 2 * SHL + WSS) * 4;  // 68096 B
 
 // U[pos][n][k] = (G g G^T)[pos] for g = W[n][.][.][k] (forward, N = Cout, K = Cin) or g = rot180(W[k][.][.][n]) (dgrad,
 // N = Cin, K = Cout); output layout [K/8][16][N][8]
@@ -75,8 +78,9 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restri
   }
 }
 
-template <int XF>
-__global__ __launch_bounds__(WNT, 1) void conv3_wino_kernel(vae_igemm_args p, const float* __restrict__ U, int tiles_x, int tiles_y) {
+template <int XF, int NB>
+__global__ __launch_bounds__(WNT, (NB == 4 ? 2 : 4)) void conv3_wino_kernel(vae_igemm_args p, const float* __restrict__ U, int tiles_x, int tiles_y) {
+  constexpr int WBN = 32 * NB;  // output channels per workgroup
   extern __shared__ __attribute__((aligned(16))) float wsm[];
   float* const sV = wsm;           // [2][SV]
   float* const sH = wsm + 2 * SV;  // [2][SHL]: the chunk's input halo, transformed
@@ -102,33 +106,40 @@ __global__ __launch_bounds__(WNT, 1) void conv3_wino_kernel(vae_igemm_args p, co
   const bool hin = hrole && ((unsigned)hy < (unsigned)g.Hs) && ((unsigned)hx < (unsigned)g.Ws);
   const auto rsA = VAE_BUF_RSRC(p.A + (int64_t)b * g.Hs * g.Ws * g.Cs, (size_t)g.Hs * g.Ws * g.Cs * 4u);
   const unsigned hbase = hin ? (unsigned)(((hy * g.Ws + hx) * g.Cs + hq * 4) * 4) : BUF_OOB;
+  // GroupNorm scale / shift rows of image b: staged in LDS once per workgroup ([2][K], behind the halo buffers), read at store time
+  float* const sS = wsm + 2 * SV + 2 * SHL;
+  if (XF != VAE_XF_NONE) {
+    for (int i = tid; i < p.K; i += WNT) {
+      sS[i] = p.scale[(int64_t)b * g.Cs + i];
+      sS[p.K + i] = p.shift[(int64_t)b * g.Cs + i];
+    }
+    __syncthreads();
+  }
   struct Halo {
-    f32x4 v, sc, sh;
+    f32x4 v;
   };
-  Halo rh{{0.f, 0.f, 0.f, 0.f}, {1.f, 1.f, 1.f, 1.f}, {0.f, 0.f, 0.f, 0.f}};
+  Halo rh{{0.f, 0.f, 0.f, 0.f}};
   auto load_halo_into = [&](int step, Halo& h) {
     const bool ok = hin && step < nsteps;
     h.v = VAE_BUF_LOAD4(rsA, ok ? hbase + (unsigned)(step * WBK * 4) : BUF_OOB);
-    if (XF != VAE_XF_NONE && ok) {
-      h.sc = *reinterpret_cast<const f32x4*>(p.scale + (int64_t)b * g.Cs + step * WBK + hq * 4);
-      h.sh = *reinterpret_cast<const f32x4*>(p.shift + (int64_t)b * g.Cs + step * WBK + hq * 4);
-    }
   };
-  auto store_halo_from = [&](float* dst, const Halo& h) {
+  auto store_halo_from = [&](float* dst, const Halo& h, int step) {
     if (!hrole) return;
     f32x4 v = h.v;
     if (XF != VAE_XF_NONE) {
+      const int c = min(step, nsteps - 1) * WBK + hq * 4;
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(&sS[c]), sh = *reinterpret_cast<const f32x4*>(&sS[p.K + c]);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float u = v[e] * h.sc[e] + h.sh[e];
+        float u = v[e] * sc[e] + sh[e];
         if (XF == VAE_XF_AFFINE_SILU) u = silu_f(u);
-        v[e] = hin ? u : 0.f;  // padding stays zero AFTER the transform
+        v[e] = (hin && step < nsteps) ? u : 0.f;  // padding stays zero AFTER the transform
       }
     }
     *reinterpret_cast<f32x4*>(&dst[hp * WBK + hq * 4]) = v;
   };
   auto load_halo = [&](int step) { load_halo_into(step, rh); };
-  auto store_halo = [&](float* dst) { store_halo_from(dst, rh); };
+  auto store_halo = [&](float* dst, int step) { store_halo_from(dst, rh, step); };
 
   // ---- V role (threads 0..255): tile vt, channel vc of the chunk: B^T d B of its 4x4 patch of the staged halo ----
   const bool vrole = tid < 256;
@@ -164,36 +175,36 @@ __global__ __launch_bounds__(WNT, 1) void conv3_wino_kernel(vae_igemm_args p, co
   const auto rsU = VAE_BUF_RSRC(U, (size_t)nsteps * 16 * p.N * 8 * 4u);
   // address = per-thread constant (one per channel block; out of range for channels beyond N) + a workgroup-uniform part in
   // a scalar register: one instruction per load
-  unsigned bvo[4];
+  unsigned bvo[NB];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) bvo[q] = (n0 + q * 32 + lr < p.N) ? (unsigned)(((n0 + q * 32 + lr) * 8 + lh * 4) * 4) : BUF_OOB;
+  for (int q = 0; q < NB; ++q) bvo[q] = (n0 + q * 32 + lr < p.N) ? (unsigned)(((n0 + q * 32 + lr) * 8 + lh * 4) * 4) : BUF_OOB;
   const unsigned bpos = (unsigned)p.N * 32u;  // bytes per position of the U image
-  auto load_b = [&](int step, f32x4 (&bq)[8]) {
+  auto load_b = [&](int step, f32x4 (&bq)[2 * NB]) {
     if (step >= nsteps) return;  // (uniform; the registers are not used again)
     const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(step * 16 + 2 * wave) * bpos);
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-      bq[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsU, bvo[i & 3], so + (i >> 2) * bpos, 0));
+    for (int i = 0; i < 2 * NB; ++i)
+      bq[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsU, bvo[i % NB], so + (i / NB) * bpos, 0));
   };
 
-  f32x16 acc[2][4];
+  f32x16 acc[2][NB];
 #pragma unroll
   for (int pi = 0; pi < 2; ++pi)
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb)
+    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[pi][nb][e] = 0.f;
 
   // prologue: halo(0), halo(1) in LDS, V(0) from halo(0); halo(2) and the U fragments of step 0 in registers
-  f32x4 bq0[8], bq1[8];
+  f32x4 bq0[2 * NB], bq1[2 * NB];
   load_b(0, bq0);
   {  // the three halo requests of the prologue go out together (one memory latency, not two)
     Halo h0 = rh, h1 = rh;
     load_halo_into(0, h0);
     load_halo_into(1, h1);
     load_halo(2);
-    store_halo_from(sH, h0);
-    store_halo_from(sH + SHL, h1);
+    store_halo_from(sH, h0, 0);
+    store_halo_from(sH + SHL, h1, 1);
   }
   __syncthreads();
   write_v(sH, sV);
@@ -202,20 +213,20 @@ __global__ __launch_bounds__(WNT, 1) void conv3_wino_kernel(vae_igemm_args p, co
   // 0..3 (which own the V transform) stage first and multiply afterwards, waves 4..7 multiply first.  Step s: V(s+1) from
   // halo(s+1) [published by the previous barrier]; halo(s+2) -> the buffer halo(s) left; requests for the U fragments of step
   // s+1 (into the register set step s-1 used) and halo(s+3).  One barrier per step: it publishes V(s+1) and halo(s+2).
-  auto multiply = [&](const f32x4* a4, const f32x4 (&bq)[8]) {
+  auto multiply = [&](const f32x4* a4, const f32x4 (&bq)[2 * NB]) {
 #pragma unroll
     for (int pi = 0; pi < 2; ++pi)
 #pragma unroll
-      for (int nb = 0; nb < 4; ++nb)
+      for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[pi][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[pi][e], bq[pi * 4 + nb][e], acc[pi][nb], 0, 0, 0);
+        for (int e = 0; e < 4; ++e) acc[pi][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[pi][e], bq[pi * NB + nb][e], acc[pi][nb], 0, 0, 0);
   };
   auto stage_next = [&](int s, int par) {
     if (s + 1 < nsteps) write_v(sH + (par ^ 1) * SHL, sV + (par ^ 1) * SV);  // V(s+1): nobody reads that buffer now
-    store_halo(sH + par * SHL);                                              // halo(s+2)
+    store_halo(sH + par * SHL, s + 2);                                       // halo(s+2)
     load_halo(s + 3);
   };
-  auto step = [&](int s, int par, const f32x4 (&cur)[8], f32x4 (&nxt)[8]) {
+  auto step = [&](int s, int par, const f32x4 (&cur)[2 * NB], f32x4 (&nxt)[2 * NB]) {
     const float* cV = sV + par * SV;
     f32x4 a4[2];
     auto read_a = [&]() {
@@ -259,7 +270,7 @@ __global__ __launch_bounds__(WNT, 1) void conv3_wino_kernel(vae_igemm_args p, co
     offp[q] = (oy < g.Ho && ox < g.Wo) ? (unsigned)(((oy * g.Wo + ox) * p.ldc + n0 + (tid & 31)) * 4) : BUF_OOB;
   }
 #pragma unroll
-  for (int nb = 0; nb < 4; ++nb) {
+  for (int nb = 0; nb < NB; ++nb) {
     // the residual values of the block are requested before the LDS round trip below, not one by one in front of each store
     const bool cok = n0 + nb * 32 + (tid & 31) < p.N;
     unsigned off[8];
@@ -342,17 +353,20 @@ bool conv3_wino_eligible(const vae_igemm_args& a) {
   if (a.tapmask != 0 || a.a_step > 1 || a.c_step > 1 || a.track != nullptr || a.out_bf16) return false;
   if (!(g.mode == VAE_MODE_FWD || g.mode == VAE_MODE_DGRAD) || g.Ho != g.Hs || g.Wo != g.Ws) return false;
   if (g.mode == VAE_MODE_DGRAD && a.xf != VAE_XF_NONE) return false;
-  if (g.Ho % WTH != 0 || g.Wo % WTW != 0 || a.K % WBK != 0 || a.K < 64 || a.N < 32 || a.N % 4 != 0 || g.Cs < a.K) return false;
+  if (g.Ho % WTH != 0 || g.Wo % WTW != 0 || a.K % WBK != 0 || a.K < 64 || a.K > 1024 || a.N < 32 || a.N % 4 != 0 || g.Cs < a.K) return false;
   if (!aligned16(a.A) || !aligned16(a.C)) return false;
   if ((size_t)g.Hs * g.Ws * g.Cs * 4u >= BUF_MAX || (size_t)g.Ho * g.Wo * a.ldc * 4u >= BUF_MAX) return false;
   if ((size_t)a.K * 16 * a.N * 4u >= BUF_MAX) return false;
   return true;
 }
 
+// channel blocks (of 32) per workgroup: 2 (64 channels, 128 VGPRs per wave, TWO workgroups per CU) or 4 (128 channels, one)
+static int wino_nb() { return getenv("VAEHIP_WINO_NB4") ? 4 : 2; }
+
 // chunks per image of the statistics epilogue (0 = not available for these arguments)
 int conv3_wino_gstat_chunks(const vae_igemm_args& a) {
   const vae_conv_geom& g = a.g;
-  if (a.gstat_groups <= 0 || a.N % WBN != 0 || a.N % a.gstat_groups != 0 || g.mode == VAE_MODE_DGRAD) return 0;
+  if (a.gstat_groups <= 0 || a.N % (32 * wino_nb()) != 0 || a.N % a.gstat_groups != 0 || g.mode == VAE_MODE_DGRAD) return 0;
   const int cpg = a.N / a.gstat_groups;
   if (cpg != 4 && cpg != 8 && cpg != 16) return 0;
   return (g.Wo / WTW) * (g.Ho / WTH);
@@ -365,26 +379,32 @@ int launch_wino_weights(const vae_igemm_args& a, float* U, hipStream_t st) {
   return 0;
 }
 
-int launch_conv3_wino(const vae_igemm_args& a, const float* U, hipStream_t st) {
+template <int XF, int NB>
+static int launch_wino_t(const vae_igemm_args& a, const float* U, hipStream_t st) {
   const vae_conv_geom& g = a.g;
   const int tx = g.Wo / WTW, ty = g.Ho / WTH;
-  const int64_t nt = (int64_t)((a.N + WBN - 1) / WBN) * tx * ty * g.B;
+  const int64_t nt = (int64_t)((a.N + 32 * NB - 1) / (32 * NB)) * tx * ty * g.B;
   if (nt > 0x7fffffffLL) return VAE_EINVAL;
-  static bool attr_set[3] = {false, false, false};
-  const int xi = a.xf == VAE_XF_NONE ? 0 : (a.xf == VAE_XF_AFFINE ? 1 : 2);
-  const void* fn = xi == 0 ? reinterpret_cast<const void*>(conv3_wino_kernel<VAE_XF_NONE>)
-                 : xi == 1 ? reinterpret_cast<const void*>(conv3_wino_kernel<VAE_XF_AFFINE>)
-                           : reinterpret_cast<const void*>(conv3_wino_kernel<VAE_XF_AFFINE_SILU>);
-  if (!attr_set[xi]) {
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, WINO_LDS) != hipSuccess) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wino_kernel<XF, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, WINO_LDS) !=
+        hipSuccess) {
       vae_set_error("conv3_wino: cannot reserve %d bytes of LDS", WINO_LDS);
       return VAE_ELAUNCH;
     }
-    attr_set[xi] = true;
+    attr_set = true;
   }
-  dim3 grid((unsigned)nt);
-  if (xi == 0) hipLaunchKernelGGL(conv3_wino_kernel<VAE_XF_NONE>, grid, dim3(WNT), WINO_LDS, st, a, U, tx, ty);
-  else if (xi == 1) hipLaunchKernelGGL(conv3_wino_kernel<VAE_XF_AFFINE>, grid, dim3(WNT), WINO_LDS, st, a, U, tx, ty);
-  else hipLaunchKernelGGL(conv3_wino_kernel<VAE_XF_AFFINE_SILU>, grid, dim3(WNT), WINO_LDS, st, a, U, tx, ty);
+  hipLaunchKernelGGL((conv3_wino_kernel<XF, NB>), dim3((unsigned)nt), dim3(WNT), WINO_LDS, st, a, U, tx, ty);
   return 0;
+}
+
+int launch_conv3_wino(const vae_igemm_args& a, const float* U, hipStream_t st) {
+  if (wino_nb() == 4) {
+    if (a.xf == VAE_XF_NONE) return launch_wino_t<VAE_XF_NONE, 4>(a, U, st);
+    if (a.xf == VAE_XF_AFFINE) return launch_wino_t<VAE_XF_AFFINE, 4>(a, U, st);
+    return launch_wino_t<VAE_XF_AFFINE_SILU, 4>(a, U, st);
+  }
+  if (a.xf == VAE_XF_NONE) return launch_wino_t<VAE_XF_NONE, 2>(a, U, st);
+  if (a.xf == VAE_XF_AFFINE) return launch_wino_t<VAE_XF_AFFINE, 2>(a, U, st);
+  return launch_wino_t<VAE_XF_AFFINE_SILU, 2>(a, U, st);
 }
