@@ -205,11 +205,16 @@ class Engine:
         if xf != XF_NONE and ops.act_image_ok(kind, x.shape, m.weight.shape[0], m.weight.shape[1]):
             # transform and round once (2 B/element written); forward and wgrad then read the image and transform nothing
             a16 = ops.gn_apply_bf16(x, st, xf)
+        xin, xfc, stc = x, xf, st
+        if a16 is None and xf != XF_NONE and tb is None and ops.act_image32_ok(kind, x.shape, m.weight.shape[0], m.weight.shape[1]):
+            # fp32 mode, wide layers: the transformed tensor once, forward and wgrad read it as is (ops.ACT_IMAGE32_MIN_CIN)
+            a16 = xin = make_in() if "t" in cache else ops.gn_apply(x, st, xf)
+            xfc, stc = XF_NONE, None
         self._last16 = a16
         # every 3x3 output of this model feeds a GroupNorm(32) next (or is summed first: then the statistics are dropped)
         want_stats = ops.GN_GROUPS if (kind in ("c3", "c3up") and (res is None or fuse_res)) else None
-        y = ops.conv_fwd(x, m.weight, m.bias, kind, xf=xf, stats=st, res=res if fuse_res else None, track=tb, a16=a16,
-                         gstat_groups=want_stats)
+        y = ops.conv_fwd(xin, m.weight, m.bias, kind, xf=xfc, stats=stc, res=res if fuse_res else None, track=tb,
+                         a16=a16 if a16 is not xin else None, gstat_groups=want_stats)
         if sinks:
             v = ops.track_final(tb, y.shape[0] * y.shape[1] * y.shape[2])
             for s in sinks:
@@ -233,6 +238,8 @@ class Engine:
             # a gradient that arrives without its bf16 image (from an upsampler, an attention block, the loss): rounding it
             # once here costs what the two consumers save in reads, and puts both on the kernels that take an image
             dy._b16 = ops.pack_bf16(dy, torch.empty(dy.shape, device=dy.device, dtype=torch.bfloat16))
+        if x16 is not None and x16.dtype == torch.float32:  # the fp32 activation image of _conv: already transformed
+            x, xf, st, x16 = x16, XF_NONE, None, None
         ops.conv_wgrad(dy, x, kind, self._g(m.weight), self._g(m.bias), xf=xf, stats=st, x16=x16)
         if need_dx:
             return ops.conv_dgrad(dy, m.weight, kind, (x.shape[1], x.shape[2]), out_bf16=dx_to_gn)

@@ -5,6 +5,7 @@ Every function enqueues on torch's current HIP stream and never synchronises.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import NamedTuple, Optional, Tuple
 
 import torch
@@ -180,6 +181,20 @@ def act_image_ok(kind: str, x_shape, Co: int, Ci: int) -> bool:
     B, H, W, Cs = x_shape
     g = _fwd_geom(kind, B, H, W, Cs)
     return bool(lib.query("vae_bf16_act_image_ok", C.byref(g), Co, Ci))
+
+
+# fp32 mode: a Winograd workgroup covers 64 output channels, so GroupNorm+SiLU fused into its halo staging is recomputed
+# Cout/64 times per element (and once more per 128 channels in the wgrad).  From 256 input channels on, writing the transformed
+# tensor once (vae_gn_apply: 8 B/element) and running forward + wgrad without a transform is cheaper (tools/microbench_wino.py:
+# 512 channels @64^2: fused forward 1.38 vs 1.20 ms, fused wgrad 1.43 vs 1.27, the extra pass 0.07 ms).
+ACT_IMAGE32_MIN_CIN = 256
+
+
+def act_image32_ok(kind: str, x_shape, Co: int, Ci: int) -> bool:
+    if PRECISION != PREC_F32 or not WINOGRAD or kind != "c3" or Ci < ACT_IMAGE32_MIN_CIN or os.environ.get("VAEHIP_NO_WINO"):
+        return False
+    B, H, W, Cs = x_shape
+    return H % 8 == 0 and W % 16 == 0 and Ci % 32 == 0 and Co % 64 == 0 and Cs == Ci
 
 
 # bf16 mode stores gradients that only feed bf16 kernels as bf16 images (the dgrad outputs of the halo-tile kernels and the
