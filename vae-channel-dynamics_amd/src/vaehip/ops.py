@@ -187,7 +187,7 @@ def act_image_ok(kind: str, x_shape, Co: int, Ci: int) -> bool:
 # Cout/64 times per element (and once more per 128 channels in the wgrad).  From 256 input channels on, writing the transformed
 # tensor once (vae_gn_apply: 8 B/element) and running forward + wgrad without a transform is cheaper (tools/microbench_wino.py:
 # 512 channels @64^2: fused forward 1.38 vs 1.20 ms, fused wgrad 1.43 vs 1.27, the extra pass 0.07 ms).
-ACT_IMAGE32_MIN_CIN = 256
+ACT_IMAGE32_MIN_CIN = int(os.environ.get("VAEHIP_ACT32_MIN_CIN", "256"))
 
 
 def act_image32_ok(kind: str, x_shape, Co: int, Ci: int) -> bool:
