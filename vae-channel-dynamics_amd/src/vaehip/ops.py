@@ -184,10 +184,12 @@ def act_image_ok(kind: str, x_shape, Co: int, Ci: int) -> bool:
 
 
 # fp32 mode: a Winograd workgroup covers 64 output channels, so GroupNorm+SiLU fused into its halo staging is recomputed
-# Cout/64 times per element (and once more per 128 channels in the wgrad).  From 256 input channels on, writing the transformed
-# tensor once (vae_gn_apply: 8 B/element) and running forward + wgrad without a transform is cheaper (tools/microbench_wino.py:
-# 512 channels @64^2: fused forward 1.38 vs 1.20 ms, fused wgrad 1.43 vs 1.27, the extra pass 0.07 ms).
-ACT_IMAGE32_MIN_CIN = int(os.environ.get("VAEHIP_ACT32_MIN_CIN", "256"))
+# Cout/64 times per element (and once more per 128 channels in the wgrad).  Writing the transformed tensor once
+# (vae_gn_apply: 8 B/element) and running forward + wgrad without a transform is cheaper (tools/microbench_wino.py, 512
+# channels @64^2: fused forward 1.38 vs 1.20 ms, fused wgrad 1.43 vs 1.27, the extra pass 0.07 ms).  Measured on the whole step
+# (bench.py, 256^2, batch 16): never 214.8 ms / 15.5 GiB peak, Cin >= 512: 209.6 / 17.7, >= 256: 207.2 / 20.7, >= 128 (all
+# of them): 205.2 ms / 25.4 GiB.  VAEHIP_ACT32_MIN_CIN overrides (a large value = always fuse: the lowest peak memory).
+ACT_IMAGE32_MIN_CIN = int(os.environ.get("VAEHIP_ACT32_MIN_CIN", "128"))
 
 
 def act_image32_ok(kind: str, x_shape, Co: int, Ci: int) -> bool:
