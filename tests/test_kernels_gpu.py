@@ -825,8 +825,9 @@ def test_winograd_forward_and_dgrad(cuda, monkeypatch, B, H, W, Ci, Co, nb4):
         dx = ops.conv_dgrad(_nhwc(dy), wd, "c3", (H, W))
     finally:
         ops.PROFILER = None
-    dgk = "conv3_wino_kernel<0>" if Co >= 64 else "igemm_rows_kernel<128,128,4,2,true,true,0>"  # the dgrad contracts over Co
-    assert [r[0] for r in prof.records] == ["conv3_wino_kernel<0>", "conv3_wino_kernel<2>", dgk], [r[0] for r in prof.records]
+    nb = 4 if nb4 else 2
+    dgk = f"conv3_wino_kernel<0,{nb}>" if Co >= 64 else "igemm_rows_kernel<128,128,4,2,true,true,0>"  # the dgrad contracts over Co
+    assert [r[0] for r in prof.records] == [f"conv3_wino_kernel<0,{nb}>", f"conv3_wino_kernel<2,{nb}>", dgk], [r[0] for r in prof.records]
     if Co % 128 == 0:  # GroupNorm moments of the output from the epilogue == those of the tensor it wrote
         assert hasattr(y1, "_gstat") and y1._gstat[2] == (H // 8) * (W // 16)
         g2, b2 = torch.ones(Co, device="cuda"), torch.zeros(Co, device="cuda")

@@ -361,12 +361,12 @@ bool conv3_wino_eligible(const vae_igemm_args& a) {
 }
 
 // channel blocks (of 32) per workgroup: 2 (64 channels, 128 VGPRs per wave, TWO workgroups per CU) or 4 (128 channels, one)
-static int wino_nb() { return getenv("VAEHIP_WINO_NB4") ? 4 : 2; }
+int conv3_wino_nb() { return getenv("VAEHIP_WINO_NB4") ? 4 : 2; }
 
 // chunks per image of the statistics epilogue (0 = not available for these arguments)
 int conv3_wino_gstat_chunks(const vae_igemm_args& a) {
   const vae_conv_geom& g = a.g;
-  if (a.gstat_groups <= 0 || a.N % (32 * wino_nb()) != 0 || a.N % a.gstat_groups != 0 || g.mode == VAE_MODE_DGRAD) return 0;
+  if (a.gstat_groups <= 0 || a.N % (32 * conv3_wino_nb()) != 0 || a.N % a.gstat_groups != 0 || g.mode == VAE_MODE_DGRAD) return 0;
   const int cpg = a.N / a.gstat_groups;
   if (cpg != 4 && cpg != 8 && cpg != 16) return 0;
   return (g.Wo / WTW) * (g.Ho / WTH);
@@ -399,7 +399,7 @@ static int launch_wino_t(const vae_igemm_args& a, const float* U, hipStream_t st
 }
 
 int launch_conv3_wino(const vae_igemm_args& a, const float* U, hipStream_t st) {
-  if (wino_nb() == 4) {
+  if (conv3_wino_nb() == 4) {
     if (a.xf == VAE_XF_NONE) return launch_wino_t<VAE_XF_NONE, 4>(a, U, st);
     if (a.xf == VAE_XF_AFFINE) return launch_wino_t<VAE_XF_AFFINE, 4>(a, U, st);
     return launch_wino_t<VAE_XF_AFFINE_SILU, 4>(a, U, st);

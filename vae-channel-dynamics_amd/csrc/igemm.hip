@@ -26,6 +26,7 @@ bool conv3_wino_eligible(const vae_igemm_args& a);                      // conv3
 int launch_wino_weights(const vae_igemm_args& a, float* U, hipStream_t st);
 int launch_conv3_wino(const vae_igemm_args& a, const float* U, hipStream_t st);
 int conv3_wino_gstat_chunks(const vae_igemm_args& a);
+int conv3_wino_nb();
 bool conv3_wide_bf16_eligible(const vae_igemm_args& a);                 // conv3_wide_bf16.hip (both operands bf16 images, 8x32 tiles)
 int conv3_wide_bf16_gstat_chunks(const vae_igemm_args& a);
 int launch_conv3_wide_bf16(const vae_igemm_args& a, hipStream_t st);
@@ -837,7 +838,7 @@ extern "C" int vae_igemm_kernel_name(const vae_igemm_args* ap, char* buf, int32_
   const bool bkm = rows_bkm(a), vec = rows_vec(a, bkm);
   const char* tf[2] = {"false", "true"};
   if (a.Wu != nullptr && rows_wino(a))
-    snprintf(buf, n, "conv3_wino_kernel<%d>", a.xf);
+    snprintf(buf, n, "conv3_wino_kernel<%d,%d>", a.xf, conv3_wino_nb());
   else if (rows_is_phase(a) && rows_use_wide_bf16(a, vec, bkm))
     snprintf(buf, n, "conv3_wide_bf16_kernel<%s,2>", tf[a.g.mode == VAE_MODE_DGRAD]);
   else if (rows_is_phase(a) && a.prec == VAE_PREC_BF16)
