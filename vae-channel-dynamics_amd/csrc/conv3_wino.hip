@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restri
 }
 
 template <int XF, int NB>
-__global__ __launch_bounds__(WNT, (NB == 4 ? 2 : 4)) void conv3_wino_kernel(vae_igemm_args p, const float* __restrict__ U, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(WNT, (NB == 4 ? 2 : 4)) void conv3_wino_kernel(vae_igemm_args p, const float* __restrict__ U, int tiles_x, int tiles_y, int xcd_sp) {
   constexpr int WBN = 32 * NB;  // output channels per workgroup
   extern __shared__ __attribute__((aligned(16))) float wsm[];
   float* const sV = wsm;           // [2][SV]
@@ -89,8 +89,18 @@ __global__ __launch_bounds__(WNT, (NB == 4 ? 2 : 4)) void conv3_wino_kernel(vae_
   const int lr = lane & 31, lh = lane >> 5;
   const vae_conv_geom g = p.g;
   const int tilesN = (p.N + WBN - 1) / WBN;
-  int t = blockIdx.x;
-  const int tn = t % tilesN; t /= tilesN;
+  // Workgroup id -> (spatial tile, channel block).  Consecutive ids go round-robin over the 8 XCDs (one L2 each).  With tn
+  // fastest an XCD sees one channel block's slice of U (what fits its L2) but every XCD pulls the whole input: Cout/64-fold
+  // L2 fills.  When the whole U image is small (<= VAEHIP_WINO_XCD_U bytes, default 4 MB: it stays in every L2 anyway) the
+  // channel blocks of a spatial tile get ids congruent mod 8 instead, so one L2 fetches that tile's halo once.
+  int t = blockIdx.x, tn;
+  if (xcd_sp) {
+    tn = (t >> 3) % tilesN;
+    t = ((t >> 3) / tilesN) * 8 + (t & 7);
+  } else {
+    tn = t % tilesN;
+    t /= tilesN;
+  }
   const int tx = t % tiles_x; t /= tiles_x;
   const int ty = t % tiles_y;
   const int b = t / tiles_y;
@@ -394,7 +404,10 @@ static int launch_wino_t(const vae_igemm_args& a, const float* U, hipStream_t st
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv3_wino_kernel<XF, NB>), dim3((unsigned)nt), dim3(WNT), WINO_LDS, st, a, U, tx, ty);
+  static const size_t xcd_u = getenv("VAEHIP_WINO_XCD_U") ? (size_t)atoll(getenv("VAEHIP_WINO_XCD_U")) : ((size_t)4 << 20);
+  const int tilesN = (a.N + 32 * NB - 1) / (32 * NB);
+  const int xcd_sp = (tilesN > 1 && (size_t)a.K * 16 * a.N * 4u <= xcd_u && ((int64_t)tx * ty * g.B) % 8 == 0) ? 1 : 0;
+  hipLaunchKernelGGL((conv3_wino_kernel<XF, NB>), dim3((unsigned)nt), dim3(WNT), WINO_LDS, st, a, U, tx, ty, xcd_sp);
   return 0;
 }
 
