@@ -90,11 +90,11 @@ __global__ __launch_bounds__(WNT, (NB == 4 ? 2 : 4)) void conv3_wino_kernel(vae_
   const vae_conv_geom g = p.g;
   const int tilesN = (p.N + WBN - 1) / WBN;
   // Workgroup id -> (spatial tile, channel block).  Consecutive ids go round-robin over the 8 XCDs (one L2 each).  With tn
-  // fastest an XCD sees one channel block's slice of U but every XCD pulls the whole input: Cout/64-fold L2 fills (1.5 GB
-  // for a 134 MB input at 512 channels).  Instead the channel blocks of a spatial tile get ids congruent mod 8: one L2 fetches
-  // that tile's halo once, and the 8 workgroups per channel block that run together on an XCD stream their U slice in step
-  // (one fill per 64 workgroups: 1.07 GB at 512 channels @64^2, 0.27 GB @32^2, 0.03 GB at 256).  Same speed either way
-  // (tools/microbench_wino.py with VAEHIP_WINO_XCD_U=0 / 4 MB / 64 MB); VAEHIP_WINO_XCD_U = largest U image mapped this way.
+  // fastest an XCD sees one channel block's slice of U (what fits its L2) but every XCD pulls the whole input: Cout/64-fold
+  // L2 fills.  When the whole U image is small (<= VAEHIP_WINO_XCD_U bytes, default 4 MB: 128 and 256 channels) the channel
+  // blocks of a spatial tile get ids congruent mod 8 instead, so one L2 fetches that tile's halo once.  Measured (rocprofv3
+  // FETCH_SIZE/WRITE_SIZE, bytes per launch averaged over the step's 96 launches): tn fastest everywhere 1351 MB, this rule
+  // 1142 MB, spatial-major everywhere (512 channels too: the U slices then cycle through L2) 1207 MB; same speed in all three.
   int t = blockIdx.x, tn;
   if (xcd_sp) {
     tn = (t >> 3) % tilesN;
@@ -406,7 +406,7 @@ static int launch_wino_t(const vae_igemm_args& a, const float* U, hipStream_t st
     }
     attr_set = true;
   }
-  static const size_t xcd_u = getenv("VAEHIP_WINO_XCD_U") ? (size_t)atoll(getenv("VAEHIP_WINO_XCD_U")) : ((size_t)64 << 20);
+  static const size_t xcd_u = getenv("VAEHIP_WINO_XCD_U") ? (size_t)atoll(getenv("VAEHIP_WINO_XCD_U")) : ((size_t)4 << 20);
   const int tilesN = (a.N + 32 * NB - 1) / (32 * NB);
   const int xcd_sp = (tilesN > 1 && (size_t)a.K * 16 * a.N * 4u <= xcd_u && ((int64_t)tx * ty * g.B) % 8 == 0) ? 1 : 0;
   hipLaunchKernelGGL((conv3_wino_kernel<XF, NB>), dim3((unsigned)nt), dim3(WNT), WINO_LDS, st, a, U, tx, ty, xcd_sp);
