@@ -96,6 +96,20 @@ def test_forward_backward_matches_oracle(pair, R, B, klw):
     print(f"R={R} worst grad rel err {worst:.2e}")
 
 
+@pytest.mark.parametrize("path", ["winograd_fused_transform", "direct_kernels"])
+@pytest.mark.parametrize("R,B,klw", [(32, 2, 1e-6), (64, 2, 1e-2)])
+def test_other_fp32_conv_paths_match_oracle(pair, monkeypatch, R, B, klw, path):
+    """the default fp32 path (Winograd kernels reading a materialised GroupNorm+SiLU tensor) is what the test above runs; the
+    two alternatives -- Winograd with the transform fused into the halo staging, and the direct halo-tile kernels -- are held
+    to the same oracle tolerances"""
+    from vaehip import ops
+    if path == "winograd_fused_transform":
+        monkeypatch.setattr(ops, "ACT_IMAGE32_MIN_CIN", 10 ** 9)
+    else:
+        monkeypatch.setattr(ops, "WINOGRAD", False)
+    test_forward_backward_matches_oracle(pair, R, B, klw)
+
+
 def test_autograd_path_equals_fast_path(pair):
     """SDXLVAEWrapper.forward + torch losses + .backward() (the reference's train.py:287-299 sequence)
     must give the same numbers as the fused path."""
