@@ -897,3 +897,36 @@ def test_winograd_wgrad(cuda, B, H, W, Ci, Co):
     assert _rel(gw0, dw0) < 2e-5 and _rel(gw1, dw1) < 2e-5 and _rel(gb0, db0) < 1e-5 and not torch.equal(gw0, dw0)
     g2, _ = run(ops.XF_NONE)  # deterministic
     assert torch.equal(g2, gw0)
+
+
+@pytest.mark.parametrize("kind,B,H,W,Ci,Co", [("c1", 2, 16, 16, 256, 128), ("c3s2", 2, 32, 32, 128, 128), ("c1", 1, 8, 8, 512, 512)])
+def test_split_flat_kernel_is_fp32_accurate(cuda, monkeypatch, kind, B, H, W, Ci, Co):
+    """fp32 flat kernels on the bf16 matrix pipe (three-term operand splits, six partial products per product; opt-in with
+    VAEHIP_SPLIT=1): against float64 torch they must be as accurate as the v_mfma_f32 kernels they replace, not merely
+    within the parity bar"""
+    from vaehip import ops
+    monkeypatch.setenv("VAEHIP_SPLIT", "1")
+    gen = torch.Generator().manual_seed(77 + Ci + Co + H)
+    x = torch.randn(B, Ci, H, W, generator=gen) * 2.0 + 0.3
+    w = torch.randn(Co, Ci, 1 if kind == "c1" else 3, 1 if kind == "c1" else 3, generator=gen) / math.sqrt(Ci * (1 if kind == "c1" else 9))
+    b = torch.randn(Co, generator=gen)
+    ref = _ref_conv(x.double(), w.double(), b.double(), kind)
+    xd, wd = _nhwc(x), _to_dev_ohwi(w)
+    dy = torch.randn(ref.shape, generator=gen)
+    prof = ops.PROFILER = ops.LaunchProfiler()
+    try:
+        y = ops.conv_fwd(xd, wd, b.cuda(), kind)
+        dx = ops.conv_dgrad(_nhwc(dy), wd, kind, (H, W))
+    finally:
+        ops.PROFILER = None
+    assert all("igemm_rows_split_kernel" in r[0] for r in prof.records), [r[0] for r in prof.records]
+    os.environ["VAEHIP_NO_SPLIT"] = "1"
+    try:
+        y0 = ops.conv_fwd(xd, wd, b.cuda(), kind)
+        dx0 = ops.conv_dgrad(_nhwc(dy), wd, kind, (H, W))
+    finally:
+        del os.environ["VAEHIP_NO_SPLIT"]
+    e_split, e_f32 = _rel(_nchw(y).double(), ref), _rel(_nchw(y0).double(), ref)
+    assert e_split < 2e-6 and e_split < 4 * e_f32 + 1e-7, (e_split, e_f32)
+    assert _rel(dx, dx0) < 3e-6
+    assert torch.equal(ops.conv_fwd(xd, wd, b.cuda(), kind), y)  # deterministic

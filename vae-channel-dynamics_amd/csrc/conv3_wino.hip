@@ -81,7 +81,8 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restri
 template <int XF, int NB>
 __global__ __launch_bounds__(WNT, (NB == 4 ? 2 : 4)) void conv3_wino_kernel(vae_igemm_args p, const float* __restrict__ U, int tiles_x, int tiles_y, int xcd_sp) {
   constexpr int WBN = 32 * NB;  // output channels per workgroup
-  extern __shared__ __attribute__((aligned(16))) float wsm[];
+  // (static: a dynamic allocation above 64 KB made igemm_split.hip's results unrepeatable when processes share the GPU)
+  __shared__ __attribute__((aligned(16))) float wsm[WINO_LDS / 4];
   float* const sV = wsm;           // [2][SV]
   float* const sH = wsm + 2 * SV;  // [2][SHL]: the chunk's input halo, transformed
 
@@ -397,19 +398,10 @@ static int launch_wino_t(const vae_igemm_args& a, const float* U, hipStream_t st
   const int tx = g.Wo / WTW, ty = g.Ho / WTH;
   const int64_t nt = (int64_t)((a.N + 32 * NB - 1) / (32 * NB)) * tx * ty * g.B;
   if (nt > 0x7fffffffLL) return VAE_EINVAL;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wino_kernel<XF, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, WINO_LDS) !=
-        hipSuccess) {
-      vae_set_error("conv3_wino: cannot reserve %d bytes of LDS", WINO_LDS);
-      return VAE_ELAUNCH;
-    }
-    attr_set = true;
-  }
   static const size_t xcd_u = getenv("VAEHIP_WINO_XCD_U") ? (size_t)atoll(getenv("VAEHIP_WINO_XCD_U")) : ((size_t)4 << 20);
   const int tilesN = (a.N + 32 * NB - 1) / (32 * NB);
   const int xcd_sp = (tilesN > 1 && (size_t)a.K * 16 * a.N * 4u <= xcd_u && ((int64_t)tx * ty * g.B) % 8 == 0) ? 1 : 0;
-  hipLaunchKernelGGL((conv3_wino_kernel<XF, NB>), dim3((unsigned)nt), dim3(WNT), WINO_LDS, st, a, U, tx, ty, xcd_sp);
+  hipLaunchKernelGGL((conv3_wino_kernel<XF, NB>), dim3((unsigned)nt), dim3(WNT), 0, st, a, U, tx, ty, xcd_sp);
   return 0;
 }
 
