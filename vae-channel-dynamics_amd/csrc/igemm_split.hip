@@ -220,16 +220,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_rows_split_kernel(vae_i
       }
     }
   };
-  auto compute = [&](int mi) {
+  // partial product `pr` of every accumulator block: consecutive MFMAs go to different accumulators (a dependent pair is
+  // four instructions apart, as in the bf16 kernels)
+  auto compute = [&](int pr) {
+    constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {0, 1, 0, 1, 2, 0};
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][0], fb[ni][0], acc[mi][ni], 0, 0, 0);
-      acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][0], fb[ni][1], acc[mi][ni], 0, 0, 0);
-      acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][1], fb[ni][0], acc[mi][ni], 0, 0, 0);
-      acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][1], fb[ni][1], acc[mi][ni], 0, 0, 0);
-      acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][0], fb[ni][2], acc[mi][ni], 0, 0, 0);
-      acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][2], fb[ni][0], acc[mi][ni], 0, 0, 0);
-    }
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][PA[pr]], fb[ni][PB[pr]], acc[mi][ni], 0, 0, 0);
   };
 
   load_regs(0);
@@ -243,9 +242,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_rows_split_kernel(vae_i
     fetch(cA, cB);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      compute(mi);
-      if (mi == 0 && s + 1 < steps) {  // staged in the shadow of the MFMAs already issued
+    for (int pr = 0; pr < 6; ++pr) {
+      compute(pr);
+      if (pr == 2 && s + 1 < steps) {  // staged in the shadow of the MFMAs already issued
         __builtin_amdgcn_sched_barrier(0);
         u16* nA = smem + ((s + 1) & 1) * STAGE;
         store_lds(nA, nA + NP * SA);
