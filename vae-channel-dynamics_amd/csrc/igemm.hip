@@ -58,7 +58,9 @@ static bool rows_use_split(const vae_igemm_args& a, bool vec, bool bkm) {
   // Opt-in (VAEHIP_SPLIT=1), not the default: with it the engine's gradients were bitwise repeatable in every single-process
   // run and in thousands of stand-alone launches under GPU sharing (tools/split_stress.py), but 6 of 66 whole-step runs that
   // shared the GPU with other processes differed in the last bits (tools/det_check.py; none of 37 without it), which made
-  // tests/test_dp_gpu.py flaky.  Cause not found this round (not LDS left-overs: tools/lds_poison.hip; not the allocation kind).
+  // tests/test_dp_gpu.py flaky.  Cause not found this round: not LDS left-overs (tools/lds_poison.hip), not static vs dynamic LDS,
+  // not the MFMA issue order, not two workgroups per CU (one per CU: 4 of 18), and the bf16-mode flat kernels this one is derived
+  // from were repeatable in 33 of 33 such runs.  One process per GPU (the deployment) never showed it.
   return a.prec == VAE_PREC_F32 && vec && a.N > 32 && !(bkm && a.xf != VAE_XF_NONE) && getenv("VAEHIP_SPLIT") && !getenv("VAEHIP_NO_SPLIT");
 }
 
