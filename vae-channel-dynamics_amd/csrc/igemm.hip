@@ -60,7 +60,9 @@ static bool rows_use_split(const vae_igemm_args& a, bool vec, bool bkm) {
   // shared the GPU with other processes differed in the last bits (tools/det_check.py; none of 37 without it), which made
   // tests/test_dp_gpu.py flaky.  Cause not found this round: not LDS left-overs (tools/lds_poison.hip), not static vs dynamic LDS,
   // not the MFMA issue order, not two workgroups per CU (one per CU: 4 of 18), and the bf16-mode flat kernels this one is derived
-  // from were repeatable in 33 of 33 such runs.  One process per GPU (the deployment) never showed it.
+  // from were repeatable in 33 of 33 such runs; nor LDS above 64 KB (a 55 KB variant: 6 of 12).  With host-serialised launches
+  // (AMD_SERIALIZE_KERNEL=3: the processes alternate between kernels, not inside them) it got MORE frequent (9 of 15), which
+  // points at state between launches rather than at wave save/restore.  One process per GPU (the deployment) never showed it.
   return a.prec == VAE_PREC_F32 && vec && a.N > 32 && !(bkm && a.xf != VAE_XF_NONE) && getenv("VAEHIP_SPLIT") && !getenv("VAEHIP_NO_SPLIT");
 }
 
