@@ -249,3 +249,28 @@ def test_accumulation_window_is_flushed_at_the_end_of_a_dataloader_pass():
     assert tr.pending_micro_batches == 1
     tr.flush()
     assert tr.pending_micro_batches == 0 and seen[-1] == 3.5 and tr.global_step == epochs * upd_per_epoch + 1
+
+
+def test_fp32_activation_image_policy(monkeypatch):
+    """which 3x3 layers read a materialised GroupNorm+SiLU tensor in fp32 mode (ops.act_image32_ok): the shapes the Winograd
+    kernels take, from ACT_IMAGE32_MIN_CIN input channels on; never in bf16 mode, never with the direct kernels selected"""
+    from vaehip import ops
+    assert ops.PRECISION == ops.PREC_F32 and ops.WINOGRAD
+    monkeypatch.delenv("VAEHIP_NO_WINO", raising=False)
+    ok = lambda kind, shape, co, ci: ops.act_image32_ok(kind, shape, co, ci)
+    assert ok("c3", (2, 32, 32, 128), 128, 128) and ok("c3", (16, 64, 64, 512), 512, 512) and ok("c3", (1, 8, 16, 256), 64, 256)
+    assert not ok("c3", (2, 32, 32, 64), 128, 64)        # below the channel threshold
+    assert not ok("c1", (2, 32, 32, 128), 128, 128)      # 1x1 / stride-2 / upsampler convolutions keep the fused transform
+    assert not ok("c3", (2, 12, 32, 128), 128, 128) and not ok("c3", (2, 32, 24, 128), 128, 128)  # H % 8, W % 16
+    assert not ok("c3", (2, 32, 32, 128), 3, 128)        # conv_out: 3 output channels
+    monkeypatch.setattr(ops, "ACT_IMAGE32_MIN_CIN", 256)
+    assert not ok("c3", (2, 32, 32, 128), 128, 128) and ok("c3", (2, 32, 32, 256), 256, 256)
+    monkeypatch.setattr(ops, "ACT_IMAGE32_MIN_CIN", 128)
+    monkeypatch.setattr(ops, "WINOGRAD", False)
+    assert not ok("c3", (2, 32, 32, 128), 128, 128)
+    monkeypatch.setattr(ops, "WINOGRAD", True)
+    monkeypatch.setenv("VAEHIP_NO_WINO", "1")
+    assert not ok("c3", (2, 32, 32, 128), 128, 128)
+    monkeypatch.delenv("VAEHIP_NO_WINO")
+    with ops.precision(ops.PREC_BF16):
+        assert not ok("c3", (2, 32, 32, 128), 128, 128)
