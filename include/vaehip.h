@@ -35,6 +35,13 @@ const char* vae_last_error(void);
 int vae_abi_version(void);
 /* sizeof(vae_conv_geom / vae_igemm_args / vae_wgrad_args) for which = 0 / 1 / 2: lets a binding verify its struct mirrors */
 int vae_sizeof_args(int32_t which);
+/* Process-wide kernel-selection switches (no launch path reads the environment): "flat_conv" (flat implicit-GEMM kernels
+ * everywhere: the second algorithm of the two-algorithm tests), "no_wino" (fp32: the direct halo-tile kernels instead of the
+ * Winograd ones: the parity reference), "no_wide" (bf16: the 128-pixel halo-tile kernel instead of the wide-tile one).
+ * Initial values come from VAEHIP_FLAT_CONV / VAEHIP_NO_WINO / VAEHIP_NO_WIDE, read ONCE when the library is loaded.
+ * vae_get_option returns the value, or -1 for an unknown name. */
+int vae_set_option(const char* name, int32_t value);
+int vae_get_option(const char* name);
 
 /* input transform applied to the A operand while it is staged into LDS */
 #define VAE_XF_NONE 0

@@ -1,6 +1,6 @@
 """BASELINE.json configs[1] at FULL size (256x256, batch 16) -- too large for the CPU oracle, so the step is checked through
 size-independent properties: (1) determinism (bitwise), (2) the halo-tile kernels against the flat implicit-GEMM kernels
-(two different algorithms, VAEHIP_FLAT_CONV=1 selects the second), (3) the batch mean: one step on 16 images equals the mean
+(two different algorithms, the library option "flat_conv" selects the second), (3) the batch mean: one step on 16 images equals the mean
 of two steps on 8 -- different tile counts, split-K plans and GroupNorm chunkings on the same math.  The same in bf16 mode
 (tile + activation-image kernels against the flat bf16 kernels): there a different summation order moves a conv output by
 ~1e-6, which flips the bf16 rounding of ~1e-3 of the next layer's operands by one ulp (0.4 %), so two correct
@@ -38,6 +38,7 @@ def _rel(a, b):
 @pytest.mark.parametrize("mode,tol,gtol", [("no", 2e-5, 2e-4), ("bf16", 5e-4, 2e-2)])
 def test_full_size_step_properties(model, mode, tol, gtol):
     import vae_oracle as vo
+    from vaehip import ops
     w = model
     eng = w.vae.engine
     eng.set_precision(mode)
@@ -51,11 +52,8 @@ def test_full_size_step_properties(model, mode, tol, gtol):
         assert torch.isfinite(s1).all() and torch.isfinite(g1).all()
 
         # (2) a different algorithm for every 3x3 layer: flat implicit GEMM instead of the halo-tile kernels
-        os.environ["VAEHIP_FLAT_CONV"] = "1"
-        try:
+        with ops.option("flat_conv"):
             sf, gf, tf = _step(w, x, eps)
-        finally:
-            del os.environ["VAEHIP_FLAT_CONV"]
         assert float((sf - s1).abs().max() / s1.abs().max()) < tol
         assert _rel(gf, g1) < gtol, _rel(gf, g1)
         for n in TRACKED:

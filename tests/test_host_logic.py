@@ -256,7 +256,7 @@ def test_fp32_activation_image_policy(monkeypatch):
     kernels take, from ACT_IMAGE32_MIN_CIN input channels on; never in bf16 mode, never with the direct kernels selected"""
     from vaehip import ops
     assert ops.PRECISION == ops.PREC_F32 and ops.WINOGRAD
-    monkeypatch.delenv("VAEHIP_NO_WINO", raising=False)
+    assert ops.get_option("no_wino") == 0 and ops.get_option("flat_conv") == 0 and ops.get_option("bogus") == -1
     ok = lambda kind, shape, co, ci: ops.act_image32_ok(kind, shape, co, ci)
     assert ok("c3", (2, 32, 32, 128), 128, 128) and ok("c3", (16, 64, 64, 512), 512, 512) and ok("c3", (1, 8, 16, 256), 64, 256)
     assert not ok("c3", (2, 32, 32, 64), 128, 64)        # below the channel threshold
@@ -269,8 +269,10 @@ def test_fp32_activation_image_policy(monkeypatch):
     monkeypatch.setattr(ops, "WINOGRAD", False)
     assert not ok("c3", (2, 32, 32, 128), 128, 128)
     monkeypatch.setattr(ops, "WINOGRAD", True)
-    monkeypatch.setenv("VAEHIP_NO_WINO", "1")
-    assert not ok("c3", (2, 32, 32, 128), 128, 128)
-    monkeypatch.delenv("VAEHIP_NO_WINO")
+    with ops.option("no_wino"):  # the library-side switch (tests compare the two fp32 algorithms with it)
+        assert ops.get_option("no_wino") == 1 and not ok("c3", (2, 32, 32, 128), 128, 128)
+    with ops.option("flat_conv"):
+        assert not ok("c3", (2, 32, 32, 128), 128, 128)
+    assert ops.get_option("no_wino") == 0 and ok("c3", (2, 32, 32, 128), 128, 128)
     with ops.precision(ops.PREC_BF16):
         assert not ok("c3", (2, 32, 32, 128), 128, 128)

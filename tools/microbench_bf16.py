@@ -53,14 +53,13 @@ def main():
             "wgrad_img": lambda: ops.conv_wgrad(dy16, x, "c3", gw, gb, x16=a16),
         }
         for variant in ("wide", "tile128"):
-            if variant == "tile128":
-                os.environ["VAEHIP_NO_WIDE"] = "1"
+            ops.lib.call("vae_set_option", b"no_wide", 1 if variant == "tile128" else 0)
             for k, fn in runs.items():
                 if variant == "tile128" and k.startswith("wgrad"):
                     continue
                 ms = timeit(fn)
                 print(f"{nm:6s} {variant:8s} {k:14s} {ms:8.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s", flush=True)
-            os.environ.pop("VAEHIP_NO_WIDE", None)
+        ops.lib.call("vae_set_option", b"no_wide", 0)
 
 
 if __name__ == "__main__":

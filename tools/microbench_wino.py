@@ -44,9 +44,8 @@ for nm in (sys.argv[1:] or list(SHAPES)):
     if os.environ.get("MB_ONLY"):
         runs = {k: v for k, v in runs.items() if k.startswith(os.environ["MB_ONLY"])}
     for variant in ("wino", "direct"):
-        if variant == "direct":
-            os.environ["VAEHIP_NO_WINO"] = "1"
+        ops.lib.call("vae_set_option", b"no_wino", 1 if variant == "direct" else 0)
         for k, fn in runs.items():
             ms = timeit(fn)
             print(f"{nm:6s} {variant:7s} {k:15s} {ms:8.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s (algorithmic)", flush=True)
-        os.environ.pop("VAEHIP_NO_WINO", None)
+    ops.lib.call("vae_set_option", b"no_wino", 0)

@@ -4,12 +4,10 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
-#include "../../include/vaehip.h"
+#include "common_host.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-void vae_set_error(const char* fmt, ...);
 
 #define VAE_CHECK(cond, ...)                 \
   do {                                       \

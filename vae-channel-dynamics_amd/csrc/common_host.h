@@ -1,0 +1,15 @@
+// Host-side declarations shared by every translation unit of libvaehip (no device code).
+#pragma once
+#include <stdint.h>
+#include "../../include/vaehip.h"
+
+void vae_set_error(const char* fmt, ...);
+
+// process-wide kernel-selection switches (error.cpp): VAEHIP_FLAT_CONV / VAEHIP_NO_WINO / VAEHIP_NO_WIDE are read once at
+// load time; vae_set_option changes them afterwards (tests compare two algorithms that way)
+struct vae_options {
+  int flat_conv;  // flat implicit-GEMM kernels everywhere (the second algorithm of the two-algorithm tests)
+  int no_wino;    // fp32: direct halo-tile kernels instead of the Winograd ones (the parity reference)
+  int no_wide;    // bf16: the 128-pixel halo-tile kernel instead of the wide-tile one
+};
+const vae_options& vae_opt();

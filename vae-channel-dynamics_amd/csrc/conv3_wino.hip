@@ -9,7 +9,7 @@
 //     contiguous 4 KB pieces.  For dgrad the kernel is rotated and transposed there (N = Cin, K = Cout).
 //   * Workgroup (8 waves) = 8 x 16 output pixels (32 Winograd tiles) x 64 output channels (NB = 2 channel blocks), channel
 //     chunk of 8 per step; 64 accumulator registers per wave, 128 VGPRs, so TWO workgroups share a CU and fill each other's
-//     barrier / load bubbles (NB = 4: 128 channels, 256 VGPRs, one workgroup per CU, was 4-10 % slower; VAEHIP_WINO_NB4=1).
+//     barrier / load bubbles (NB = 4: 128 channels, 256 VGPRs, one workgroup per CU, was 4-10 % slower and is not built).
 //     Threads 0..359 load the chunk's 10 x 18 input halo once (GroupNorm + SiLU applied once per element) into LDS two steps
 //     ahead; threads 0..255 each own one (tile, channel) of the chunk, take B^T d B of the 4x4 patch (32 additions) and write
 //     the 16 values into the V image [16][32][8] (double buffered).  Wave w multiplies positions 2w, 2w+1: per position ONE
@@ -81,7 +81,6 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restri
 template <int XF, int NB>
 __global__ __launch_bounds__(WNT, (NB == 4 ? 2 : 4)) void conv3_wino_kernel(vae_igemm_args p, const float* __restrict__ U, int tiles_x, int tiles_y, int xcd_sp) {
   constexpr int WBN = 32 * NB;  // output channels per workgroup
-  // (static: a dynamic allocation above 64 KB made igemm_split.hip's results unrepeatable when processes share the GPU)
   __shared__ __attribute__((aligned(16))) float wsm[WINO_LDS / 4];
   float* const sV = wsm;           // [2][SV]
   float* const sH = wsm + 2 * SV;  // [2][SHL]: the chunk's input halo, transformed
@@ -92,7 +91,7 @@ __global__ __launch_bounds__(WNT, (NB == 4 ? 2 : 4)) void conv3_wino_kernel(vae_
   const int tilesN = (p.N + WBN - 1) / WBN;
   // Workgroup id -> (spatial tile, channel block).  Consecutive ids go round-robin over the 8 XCDs (one L2 each).  With tn
   // fastest an XCD sees one channel block's slice of U (what fits its L2) but every XCD pulls the whole input: Cout/64-fold
-  // L2 fills.  When the whole U image is small (<= VAEHIP_WINO_XCD_U bytes, default 4 MB: 128 and 256 channels) the channel
+  // L2 fills.  When the whole U image is small (<= 4 MB: 128 and 256 channels) the channel
   // blocks of a spatial tile get ids congruent mod 8 instead, so one L2 fetches that tile's halo once.  Measured (rocprofv3
   // FETCH_SIZE/WRITE_SIZE, bytes per launch averaged over the step's 96 launches): tn fastest everywhere 1351 MB, this rule
   // 1142 MB, spatial-major everywhere (512 channels too: the U slices then cycle through L2) 1207 MB; same speed in all three.
@@ -373,8 +372,9 @@ bool conv3_wino_eligible(const vae_igemm_args& a) {
   return true;
 }
 
-// channel blocks (of 32) per workgroup: 2 (64 channels, 128 VGPRs per wave, TWO workgroups per CU) or 4 (128 channels, one)
-int conv3_wino_nb() { return getenv("VAEHIP_WINO_NB4") ? 4 : 2; }
+// channel blocks (of 32) per workgroup: 2 = 64 channels, 128 VGPRs per wave, TWO workgroups per CU (the template also
+// instantiates with 4 = 128 channels, one workgroup per CU: measured 4-10 % slower in round 2 and no longer built)
+int conv3_wino_nb() { return 2; }
 
 // chunks per image of the statistics epilogue (0 = not available for these arguments)
 int conv3_wino_gstat_chunks(const vae_igemm_args& a) {
@@ -398,7 +398,7 @@ static int launch_wino_t(const vae_igemm_args& a, const float* U, hipStream_t st
   const int tx = g.Wo / WTW, ty = g.Ho / WTH;
   const int64_t nt = (int64_t)((a.N + 32 * NB - 1) / (32 * NB)) * tx * ty * g.B;
   if (nt > 0x7fffffffLL) return VAE_EINVAL;
-  static const size_t xcd_u = getenv("VAEHIP_WINO_XCD_U") ? (size_t)atoll(getenv("VAEHIP_WINO_XCD_U")) : ((size_t)4 << 20);
+  constexpr size_t xcd_u = (size_t)4 << 20;  // U images up to 4 MB: the channel blocks of a tile share an XCD (lowest measured traffic)
   const int tilesN = (a.N + 32 * NB - 1) / (32 * NB);
   const int xcd_sp = (tilesN > 1 && (size_t)a.K * 16 * a.N * 4u <= xcd_u && ((int64_t)tx * ty * g.B) % 8 == 0) ? 1 : 0;
   hipLaunchKernelGGL((conv3_wino_kernel<XF, NB>), dim3((unsigned)nt), dim3(WNT), 0, st, a, U, tx, ty, xcd_sp);
@@ -406,11 +406,6 @@ static int launch_wino_t(const vae_igemm_args& a, const float* U, hipStream_t st
 }
 
 int launch_conv3_wino(const vae_igemm_args& a, const float* U, hipStream_t st) {
-  if (conv3_wino_nb() == 4) {
-    if (a.xf == VAE_XF_NONE) return launch_wino_t<VAE_XF_NONE, 4>(a, U, st);
-    if (a.xf == VAE_XF_AFFINE) return launch_wino_t<VAE_XF_AFFINE, 4>(a, U, st);
-    return launch_wino_t<VAE_XF_AFFINE_SILU, 4>(a, U, st);
-  }
   if (a.xf == VAE_XF_NONE) return launch_wino_t<VAE_XF_NONE, 2>(a, U, st);
   if (a.xf == VAE_XF_AFFINE) return launch_wino_t<VAE_XF_AFFINE, 2>(a, U, st);
   return launch_wino_t<VAE_XF_AFFINE_SILU, 2>(a, U, st);

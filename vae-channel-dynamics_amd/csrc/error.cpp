@@ -1,7 +1,9 @@
-// thread-local last-error string of the C ABI
+// thread-local last-error string of the C ABI, ABI version, process-wide kernel-selection switches
 #include <stdarg.h>
 #include <stdio.h>
-#include "../../include/vaehip.h"
+#include <stdlib.h>
+#include <string.h>
+#include "common_host.h"
 
 static thread_local char g_err[512] = "";
 
@@ -12,8 +14,41 @@ void vae_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// Switches: read from the environment ONCE (when the library is loaded), afterwards changed only through vae_set_option.
+// No launch path calls getenv().
+static vae_options init_options() {
+  vae_options o;
+  o.flat_conv = getenv("VAEHIP_FLAT_CONV") ? 1 : 0;
+  o.no_wino = getenv("VAEHIP_NO_WINO") ? 1 : 0;
+  o.no_wide = getenv("VAEHIP_NO_WIDE") ? 1 : 0;
+  return o;
+}
+static vae_options g_opt = init_options();
+const vae_options& vae_opt() { return g_opt; }
+
+static int* option_slot(const char* name) {
+  if (!name) return nullptr;
+  if (!strcmp(name, "flat_conv")) return &g_opt.flat_conv;
+  if (!strcmp(name, "no_wino")) return &g_opt.no_wino;
+  if (!strcmp(name, "no_wide")) return &g_opt.no_wide;
+  return nullptr;
+}
+
 extern "C" const char* vae_last_error(void) { return g_err; }
-extern "C" int vae_abi_version(void) { return 8; }
+extern "C" int vae_abi_version(void) { return 9; }
 extern "C" int vae_sizeof_args(int32_t which) {
   return which == 0 ? (int)sizeof(vae_conv_geom) : which == 1 ? (int)sizeof(vae_igemm_args) : which == 2 ? (int)sizeof(vae_wgrad_args) : -1;
+}
+extern "C" int vae_set_option(const char* name, int32_t value) {
+  int* s = option_slot(name);
+  if (!s) {
+    vae_set_error("set_option: unknown option '%s' (flat_conv, no_wino, no_wide)", name ? name : "(null)");
+    return VAE_EINVAL;
+  }
+  *s = value ? 1 : 0;
+  return VAE_OK;
+}
+extern "C" int vae_get_option(const char* name) {
+  int* s = option_slot(name);
+  return s ? *s : -1;
 }

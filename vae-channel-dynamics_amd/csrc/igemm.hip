@@ -51,20 +51,6 @@ int wgrad_smallk_tiles(const vae_wgrad_args& a);
 int launch_wgrad_smallk(const vae_wgrad_args& a, hipStream_t st);
 int launch_rows_bf16(const vae_igemm_args& a, bool bkm, hipStream_t st);   // igemm_bf16.hip (vectorised shapes only)
 int launch_wgrad_bf16(const vae_wgrad_args& a, hipStream_t st);
-int launch_rows_split(const vae_igemm_args& a, bool bkm, hipStream_t st);  // igemm_split.hip (fp32 via three-term bf16 splits)
-// fp32 flat rows kernel on the bf16 matrix pipe (three-term splits): vectorised shapes wider than 32 columns; n-contiguous
-// weights carry no input transform there (as in the bf16 kernels)
-static bool rows_use_split(const vae_igemm_args& a, bool vec, bool bkm) {
-  // Opt-in (VAEHIP_SPLIT=1), not the default: with it the engine's gradients were bitwise repeatable in every single-process
-  // run and in thousands of stand-alone launches under GPU sharing (tools/split_stress.py), but 6 of 66 whole-step runs that
-  // shared the GPU with other processes differed in the last bits (tools/det_check.py; none of 37 without it), which made
-  // tests/test_dp_gpu.py flaky.  Cause not found this round: not LDS left-overs (tools/lds_poison.hip), not static vs dynamic LDS,
-  // not the MFMA issue order, not two workgroups per CU (one per CU: 4 of 18), and the bf16-mode flat kernels this one is derived
-  // from were repeatable in 33 of 33 such runs; nor LDS above 64 KB (a 55 KB variant: 6 of 12).  With host-serialised launches
-  // (AMD_SERIALIZE_KERNEL=3: the processes alternate between kernels, not inside them) it got MORE frequent (9 of 15), which
-  // points at state between launches rather than at wave save/restore.  One process per GPU (the deployment) never showed it.
-  return a.prec == VAE_PREC_F32 && vec && a.N > 32 && !(bkm && a.xf != VAE_XF_NONE) && getenv("VAEHIP_SPLIT") && !getenv("VAEHIP_NO_SPLIT");
-}
 
 namespace {
 
@@ -696,9 +682,9 @@ static bool wgrad_vec(const vae_wgrad_args& a) {
   return vec;
 }
 static bool wgrad_is_phase(const vae_wgrad_args& a) { return a.tapmask != 0 || a.y_step > 1; }
-static bool wgrad_use_tile(const vae_wgrad_args& a) { return wgrad3_tile_eligible(a, wgrad_vec(a)) && !getenv("VAEHIP_FLAT_CONV"); }
+static bool wgrad_use_tile(const vae_wgrad_args& a) { return wgrad3_tile_eligible(a, wgrad_vec(a)) && !vae_opt().flat_conv; }
 static bool wgrad_use_tile_bf16(const vae_wgrad_args& a) {
-  return a.prec == VAE_PREC_BF16 && wgrad3_tile_bf16_eligible(a, wgrad_vec(a)) && !getenv("VAEHIP_FLAT_CONV");
+  return a.prec == VAE_PREC_BF16 && wgrad3_tile_bf16_eligible(a, wgrad_vec(a)) && !vae_opt().flat_conv;
 }
 
 // split-K plan: which nsplit to use for these arguments (a->nsplit is ignored) and whether a->xf can be fused.
@@ -753,7 +739,7 @@ static bool rows_vec(const vae_igemm_args& a, bool bkm) {
   return vec;
 }
 static bool rows_use_tile(const vae_igemm_args& a, bool vec, bool bkm) {
-  return conv3_tile_eligible(a, vec, bkm) && !getenv("VAEHIP_FLAT_CONV");
+  return conv3_tile_eligible(a, vec, bkm) && !vae_opt().flat_conv;
 }
 // the bf16 halo-tile kernel reads the weights from their bf16 image; without one the bf16 flat kernel serves the layer
 static bool rows_use_tile_bf16(const vae_igemm_args& a, bool vec, bool bkm) {
@@ -762,13 +748,13 @@ static bool rows_use_tile_bf16(const vae_igemm_args& a, bool vec, bool bkm) {
 
 // the wide-tile kernel serves a layer the 128-pixel bf16 halo-tile kernel would serve, when both operands are bf16 images
 static bool rows_use_wide_bf16(const vae_igemm_args& a, bool vec, bool bkm) {
-  return rows_use_tile_bf16(a, vec, bkm) && conv3_wide_bf16_eligible(a) && !getenv("VAEHIP_NO_WIDE");
+  return rows_use_tile_bf16(a, vec, bkm) && conv3_wide_bf16_eligible(a) && !vae_opt().no_wide;
 }
 
 // both the forward and the wgrad of this 3x3 stride-1 layer run on the bf16 halo-tile kernels (which can read a bf16
 // activation image); pointers are placeholders with the alignment the real ones must have
 extern "C" int vae_bf16_act_image_ok(const vae_conv_geom* gp, int32_t Cout, int32_t Cin) {
-  if (!gp || getenv("VAEHIP_FLAT_CONV") || getenv("VAEHIP_NO_ACT16")) return 0;
+  if (!gp || vae_opt().flat_conv) return 0;
   const vae_conv_geom& g = *gp;
   if (g.mode != VAE_MODE_FWD || Cin % 8 != 0 || g.Cs != Cin) return 0;
   static const float dummy[4] __attribute__((aligned(16))) = {0.f, 0.f, 0.f, 0.f};
@@ -786,7 +772,7 @@ extern "C" int vae_bf16_act_image_ok(const vae_conv_geom* gp, int32_t Cout, int3
 // the output gradient of this 3x3 stride-1 layer may be handed over as a bf16 image: its dgrad (A16) and its weight
 // gradient (dY16) both run on the bf16 halo-tile kernels
 extern "C" int vae_bf16_grad_image_ok(const vae_conv_geom* gp, int32_t Cout, int32_t Cin) {
-  if (!gp || getenv("VAEHIP_FLAT_CONV") || getenv("VAEHIP_NO_GRAD16")) return 0;
+  if (!gp || vae_opt().flat_conv) return 0;
   const vae_conv_geom& g = *gp;
   if (g.mode != VAE_MODE_FWD || g.taps != 9 || g.stride != 1 || Cin % 8 != 0 || Cout % 8 != 0 || g.Ho != g.Hs || g.Wo != g.Ws) return 0;
   static const float dummy[4] __attribute__((aligned(16))) = {0.f, 0.f, 0.f, 0.f};
@@ -805,8 +791,8 @@ extern "C" int vae_bf16_grad_image_ok(const vae_conv_geom* gp, int32_t Cout, int
 static bool rows_is_phase(const vae_igemm_args& a) { return a.tapmask != 0 || a.a_step > 1 || a.c_step > 1; }
 static bool rows_wino(const vae_igemm_args& a) {
   const bool bkm = rows_bkm(a);
-  return conv3_wino_eligible(a) && rows_vec(a, bkm) && !conv_smallk_eligible(a) && !conv_smalln_eligible(a) && !getenv("VAEHIP_FLAT_CONV") &&
-         !getenv("VAEHIP_NO_WINO");
+  return conv3_wino_eligible(a) && rows_vec(a, bkm) && !conv_smallk_eligible(a) && !conv_smalln_eligible(a) && !vae_opt().flat_conv &&
+         !vae_opt().no_wino;
 }
 extern "C" int vae_wino_ok(const vae_igemm_args* ap) { return (ap && rows_wino(*ap)) ? 1 : 0; }
 extern "C" int64_t vae_wino_weight_floats(const vae_igemm_args* ap) { return ap ? (int64_t)16 * ap->N * ap->K : 0; }
@@ -872,8 +858,6 @@ extern "C" int vae_igemm_kernel_name(const vae_igemm_args* ap, char* buf, int32_
     snprintf(buf, n, "conv3_tile_kernel<%s,%s,%s,%d>", tf[bkm], tf[a.g.mode == VAE_MODE_DGRAD], tf[a.g.mode == VAE_MODE_UP2X], a.xf);
   else if (a.prec == VAE_PREC_BF16 && vec)
     snprintf(buf, n, "igemm_rows_bf16_kernel<%s,%s,%d>", a.N <= 32 ? "128,32,4,1" : "128,128,4,2", tf[bkm], a.xf);
-  else if (rows_use_split(a, vec, bkm))
-    snprintf(buf, n, "igemm_rows_split_kernel<128,128,2,2,%s,%d>", tf[bkm], a.xf);
   else if (a.N <= 32)
     snprintf(buf, n, "igemm_rows_kernel<128,32,4,1,%s,%s,%d>", tf[bkm], tf[vec], a.xf);
   else
@@ -974,8 +958,6 @@ extern "C" int vae_igemm_rows(const vae_igemm_args* ap, void* stream) {
   if (a.prec == VAE_PREC_BF16 && vec) {
     VAE_CHECK(!bkm || a.xf == VAE_XF_NONE, "igemm_rows: xf unsupported with n-contiguous weights");
     rc = launch_rows_bf16(a, bkm, st);
-  } else if (rows_use_split(a, vec, bkm)) {
-    rc = launch_rows_split(a, bkm, st);
   } else {
     rc = (a.N <= 32) ? launch_rows<128, 32, 4, 1>(a, bkm, vec, st) : launch_rows<128, 128, 4, 2>(a, bkm, vec, st);
   }
@@ -989,7 +971,7 @@ extern "C" int vae_igemm_rows(const vae_igemm_args* ap, void* stream) {
 extern "C" int vae_wgrad_wino_plan(const vae_wgrad_args* ap, int32_t* nsplit) {
   VAE_CHECK(ap && nsplit, "wgrad_wino_plan: null argument");
   *nsplit = 0;
-  if (!wgrad3_wino_eligible(*ap) || getenv("VAEHIP_FLAT_CONV") || getenv("VAEHIP_NO_WINO")) return VAE_OK;
+  if (!wgrad3_wino_eligible(*ap) || vae_opt().flat_conv || vae_opt().no_wino) return VAE_OK;
   const int64_t units = wgrad3_wino_units(ap->g);
   const int64_t wgs = (int64_t)(ap->M / 128) * (ap->N / 32);
   *nsplit = (int32_t)std::max<int64_t>(1, std::min<int64_t>(256 / std::max<int64_t>(wgs, 1), units / 8));  // one 8-wave workgroup per CU

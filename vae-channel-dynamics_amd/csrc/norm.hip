@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void gn_stats_final_kernel(const float* __rest
     if (part_ < parts)
       for (int c = part_; c < nchunk; c += parts) {
         const float* o = ws + (((int64_t)b * nchunk + c) * G + g_) * 2;
-        const double nk = (double)(min(HW, (c + 1) * per) - c * per) * (double)cpg_;
+        const double nk = (double)max(0, min(HW, (c + 1) * per) - c * per) * (double)cpg_;  // trailing chunks can start beyond HW: empty
         S += nk * (double)o[0];
       }
     sS[threadIdx.x] = S;
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void gn_stats_final_kernel(const float* __rest
     if (part_ < parts)
       for (int c = part_; c < nchunk; c += parts) {
         const float* o = ws + (((int64_t)b * nchunk + c) * G + g_) * 2;
-        const double nk = (double)(min(HW, (c + 1) * per) - c * per) * (double)cpg_;
+        const double nk = (double)max(0, min(HW, (c + 1) * per) - c * per) * (double)cpg_;  // trailing chunks can start beyond HW: empty
         const double d = (double)o[0] - m;
         Q += (double)o[1] + nk * d * d;
       }

@@ -197,8 +197,7 @@ __global__ __launch_bounds__(NT) void wgrad_smallk_kernel(vae_wgrad_args p, vae_
 bool conv_smallk_eligible(const vae_igemm_args& a) {
   const vae_conv_geom& g = a.g;
   return a.K <= 4 && a.batch == 1 && a.xf == VAE_XF_NONE && a.res == nullptr && a.alpha == 1.0f && g.taps <= TAPS_MAX &&
-         g.mode != VAE_MODE_DGRAD_S2 && (size_t)a.M * a.ldc * 4u < BUF_MAX && (size_t)g.B * g.Hs * g.Ws * g.Cs * 4u < BUF_MAX &&
-         !getenv("VAEHIP_NO_SKINNY");
+         g.mode != VAE_MODE_DGRAD_S2 && (size_t)a.M * a.ldc * 4u < BUF_MAX && (size_t)g.B * g.Hs * g.Ws * g.Cs * 4u < BUF_MAX;
 }
 int launch_conv_smallk(const vae_igemm_args& a, hipStream_t st) {
   dim3 grid((unsigned)((a.M + TP - 1) / TP), (unsigned)((a.N + 127) / 128));
@@ -209,7 +208,7 @@ int launch_conv_smallk(const vae_igemm_args& a, hipStream_t st) {
 // 0 = not served here, 1 = the narrow side is X (N <= 4), 2 = the narrow side is dY (M <= 4)
 int wgrad_smallk_kind(const vae_wgrad_args& a) {
   const vae_conv_geom& g = a.g;
-  if (a.batch != 1 || g.taps > TAPS_MAX || getenv("VAEHIP_NO_SKINNY")) return 0;
+  if (a.batch != 1 || g.taps > TAPS_MAX) return 0;
   if ((size_t)a.npix * a.ldy * 4u >= BUF_MAX || (size_t)g.B * g.Hs * g.Ws * g.Cs * 4u >= BUF_MAX) return 0;
   if (a.N <= 4 && a.xf == VAE_XF_NONE && (g.mode == VAE_MODE_FWD || g.mode == VAE_MODE_UP2X)) return 1;
   // transposed gather: plain stride-1 'same' geometry only (every input pixel is the centre tap of one output pixel)
@@ -356,7 +355,7 @@ bool conv_smalln_eligible(const vae_igemm_args& a) {
          a.A16 == nullptr && g.mode == VAE_MODE_FWD && g.taps == 9 && g.stride == 1 && g.pad_t == 1 && g.pad_l == 1 &&
          g.Ho == g.Hs && g.Wo == g.Ws && g.Wo % NTW == 0 && g.Ho % NTH == 0 && a.sk == 1 && g.Cs % 4 == 0 && aligned16(a.A) &&
          (a.xf == VAE_XF_NONE || (aligned16(a.scale) && aligned16(a.shift))) &&
-         (size_t)g.Hs * g.Ws * g.Cs * 4u < BUF_MAX && (size_t)g.Ho * g.Wo * a.ldc * 4u < BUF_MAX && !getenv("VAEHIP_NO_SKINNY");
+         (size_t)g.Hs * g.Ws * g.Cs * 4u < BUF_MAX && (size_t)g.Ho * g.Wo * a.ldc * 4u < BUF_MAX;
 }
 int launch_conv_smalln(const vae_igemm_args& a, hipStream_t st) {
   const int tx = a.g.Wo / NTW, ty = a.g.Ho / NTH;

@@ -41,10 +41,12 @@ class WgradArgs(C.Structure):
 
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
-EXPECTED_ABI = 8  # vae_abi_version() of the library these structures and signatures describe
+EXPECTED_ABI = 9  # vae_abi_version() of the library these structures and signatures describe
 
 # name -> argtypes (every function returns int); must list EVERY symbol of include/vaehip.h
 SIGNATURES = {
+    "vae_set_option": [C.c_char_p, i32],
+    "vae_get_option": [C.c_char_p],
     "vae_igemm_rows": [C.POINTER(IgemmArgs), vp],
     "vae_conv_gstat_chunks": [C.POINTER(IgemmArgs)],
     "vae_conv_phase_ok": [C.POINTER(IgemmArgs)],

@@ -55,30 +55,57 @@ class precision:
         global PRECISION
         PRECISION = self.prev
         return False
+
+
+class option:
+    """context manager over the library's process-wide kernel-selection switches (vae_set_option: "flat_conv", "no_wino",
+    "no_wide"); the environment (VAEHIP_FLAT_CONV / VAEHIP_NO_WINO / VAEHIP_NO_WIDE) only gives their initial values"""
+
+    def __init__(self, name: str, value: int = 1):
+        self.name, self.value = name.encode(), int(value)
+
+    def __enter__(self):
+        self.prev = lib.query("vae_get_option", self.name)
+        lib.call("vae_set_option", self.name, self.value)
+
+    def __exit__(self, *exc):
+        lib.call("vae_set_option", self.name, self.prev)
+        return False
+
+
+def get_option(name: str) -> int:
+    return int(lib.query("vae_get_option", name.encode()))
+
+
 MODE_FWD, MODE_UP2X, MODE_DGRAD, MODE_DGRAD_S2 = 0, 1, 2, 3
 GN_GROUPS = 32
 GN_EPS = 1e-6
 
 
 class LaunchProfiler:
-    """optional HIP-event timing of the contraction kernels, per template instantiation
-    (used by bench.py for the live roofline figure; events go on the launch stream)."""
+    """optional HIP-event timing per kernel instantiation (bench.py's live roofline figures; events go on the launch
+    stream).  A record carries two FLOP counts: `flops` = the ALGORITHMIC work of the reference formulation (direct
+    convolution: 9 taps, also for an upsampler's phase launches) and `executed` = the multiply-adds the kernel really
+    issues on the matrix pipe (16/36 of that for the Winograd kernels, the taps of its mask for a phase convolution).
+    HBM-bound helpers (reductions) are recorded with zero FLOPs."""
 
     def __init__(self):
-        self.records = []  # (key, flops, start_event, end_event)
+        self.records = []  # (key, flops, executed, start_event, end_event)
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for key, flops, e0, e1 in self.records:
-            d = out.setdefault(key, {"launches": 0, "flops": 0.0, "ms": 0.0})
+        for key, flops, executed, e0, e1 in self.records:
+            d = out.setdefault(key, {"launches": 0, "flops": 0.0, "executed": 0.0, "ms": 0.0})
             d["launches"] += 1
             d["flops"] += flops
+            d["executed"] += executed
             d["ms"] += e0.elapsed_time(e1)
         return out
 
 
 PROFILER: Optional[LaunchProfiler] = None
+WINO_EXECUTED = 16.0 / 36.0  # F(2x2,3x3) / F(3x3,2x2): 16 multiplications per 36 direct multiply-adds
 
 
 def _kernel_name(fn: str, a) -> str:
@@ -87,30 +114,39 @@ def _kernel_name(fn: str, a) -> str:
     return buf.value.decode()
 
 
+def _timed(key, flops: float, executed: float, fn: str, *args):
+    """lib.call(fn, *args), bracketed by two events on the launch stream when a profiler is installed; `key` may be a
+    callable (evaluated only when profiling)"""
+    if PROFILER is None:
+        lib.call(fn, *args)
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    lib.call(fn, *args)
+    e1.record()
+    PROFILER.records.append((key() if callable(key) else key, flops, executed, e0, e1))
+
+
 def _launch_igemm(a: IgemmArgs):
     if PROFILER is None:
         lib.call("vae_igemm_rows", C.byref(a), _stream())
         return
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    lib.call("vae_igemm_rows", C.byref(a), _stream())
-    e1.record()
-    # taps per row the launch really multiplies (the roofline figure prices executed MFMA work): the parity-class stride-2
-    # dgrad meets 9/4 taps per row on average, a phase convolution of an upsampler only those of its tap mask
-    taps = 2.25 if a.g.mode == MODE_DGRAD_S2 else (bin(a.tapmask).count("1") if a.tapmask else a.g.taps)
-    PROFILER.records.append((_kernel_name("vae_igemm_kernel_name", a), 2.0 * a.M * a.N * a.K * taps * a.batch, e0, e1))
+    # executed taps per row: the parity-class stride-2 dgrad meets 9/4 taps per row on average (that IS the direct
+    # convolution's count), a phase convolution of an upsampler only those of its tap mask (algorithmic: all 9 at high resolution)
+    taps = 2.25 if a.g.mode == MODE_DGRAD_S2 else a.g.taps
+    ex_taps = bin(a.tapmask).count("1") if a.tapmask else taps
+    name = _kernel_name("vae_igemm_kernel_name", a)
+    base = 2.0 * a.M * a.N * a.K * a.batch
+    _timed(name, base * taps, base * ex_taps * (WINO_EXECUTED if "wino" in name else 1.0), "vae_igemm_rows", C.byref(a), _stream())
 
 
 def _launch_wgrad(a: WgradArgs):
     if PROFILER is None:
         lib.call("vae_wgrad", C.byref(a), _stream())
         return
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    lib.call("vae_wgrad", C.byref(a), _stream())
-    e1.record()
-    taps = bin(a.tapmask).count("1") if a.tapmask else a.g.taps  # executed taps (phase convolutions compute 4 of 9)
-    PROFILER.records.append((_kernel_name("vae_wgrad_kernel_name", a), 2.0 * a.M * a.N * a.npix * taps * a.batch, e0, e1))
+    ex_taps = bin(a.tapmask).count("1") if a.tapmask else a.g.taps
+    base = 2.0 * a.M * a.N * a.npix * a.batch
+    _timed(_kernel_name("vae_wgrad_kernel_name", a), base * a.g.taps, base * ex_taps, "vae_wgrad", C.byref(a), _stream())
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -193,7 +229,7 @@ ACT_IMAGE32_MIN_CIN = int(os.environ.get("VAEHIP_ACT32_MIN_CIN", "128"))
 
 
 def act_image32_ok(kind: str, x_shape, Co: int, Ci: int) -> bool:
-    if PRECISION != PREC_F32 or not WINOGRAD or kind != "c3" or Ci < ACT_IMAGE32_MIN_CIN or os.environ.get("VAEHIP_NO_WINO"):
+    if PRECISION != PREC_F32 or not WINOGRAD or kind != "c3" or Ci < ACT_IMAGE32_MIN_CIN or get_option("no_wino") or get_option("flat_conv"):
         return False
     B, H, W, Cs = x_shape
     return H % 8 == 0 and W % 16 == 0 and Ci % 32 == 0 and Co % 64 == 0 and Cs == Ci
@@ -230,7 +266,7 @@ def gn_apply_bf16(x: torch.Tensor, st: "Stats", xf: int) -> torch.Tensor:
 
 
 # fp32 mode: forward and dgrad of the plain 3x3 stride-1 layers as Winograd F(2x2,3x3) (16 instead of 36 multiplications per
-# 2x2 outputs; csrc/conv3_wino.hip).  False = the direct halo-tile kernels (also what VAEHIP_NO_WINO=1 selects in the library)
+# 2x2 outputs; csrc/conv3_wino.hip).  False = the direct halo-tile kernels (also what the library option "no_wino" selects)
 WINOGRAD = True
 
 
@@ -547,16 +583,11 @@ def _wgrad_wino(a: WgradArgs, gv: torch.Tensor, bgrad_out: Optional[torch.Tensor
     slab = torch.empty((ns, 16 * a.N * a.M), device=dev, dtype=torch.float32)
     bpart = torch.empty((ns, a.M), device=dev, dtype=torch.float32) if bgrad_out is not None else None
     a.nsplit, a.partial, a.bias_partial = ns, _p(slab), _p(bpart)
-    if PROFILER is None:
-        lib.call("vae_wgrad_wino", C.byref(a), _stream())
-    else:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        lib.call("vae_wgrad_wino", C.byref(a), _stream())
-        e1.record()
-        PROFILER.records.append((f"wgrad3_wino_kernel<{a.xf}>", 2.0 * a.M * a.N * a.npix * 9, e0, e1))
+    fl = 2.0 * a.M * a.N * a.npix * 9
+    _timed(f"wgrad3_wino_kernel<{a.xf}>", fl, fl * WINO_EXECUTED, "vae_wgrad_wino", C.byref(a), _stream())
     scratch = torch.empty((16 * a.N * a.M,), device=dev, dtype=torch.float32) if ns > 1 else None
-    lib.call("vae_wgrad_wino_reduce", _p(slab), ns, a.N, a.M, _p(scratch), _p(gv), _p(bpart), _p(bgrad_out), _stream())
+    _timed("wgrad_wino_reduce (split sum + output transform)", 0.0, 0.0, "vae_wgrad_wino_reduce", _p(slab), ns, a.N, a.M,
+           _p(scratch), _p(gv), _p(bpart), _p(bgrad_out), _stream())
     return True
 
 
@@ -787,7 +818,9 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float):
     qe, ke, ve = _attn_operand(q), _attn_operand(k), _attn_operand(v)
     o = torch.empty_like(q)
     lse = torch.empty((B, T), device=q.device, dtype=torch.float32)
-    lib.call("vae_attn_fwd", _p(qe), _p(ke), _p(ve), B, T, Cc, float(scale), PRECISION, _p(o), _p(lse), _stream())
+    fl = 4.0 * B * T * T * Cc  # Q K^T and P V
+    _timed(f"attn_fwd_kernel<{'bf16' if PRECISION == PREC_BF16 else 'f32'}>", fl, fl, "vae_attn_fwd", _p(qe), _p(ke), _p(ve), B, T, Cc,
+           float(scale), PRECISION, _p(o), _p(lse), _stream())
     ATTN_CALLS["blockwise_fwd"] += 1
     return o, (qe, ke, ve, lse, PRECISION)
 
@@ -801,8 +834,10 @@ def attn_bwd(saved, o: torch.Tensor, do: torch.Tensor, scale: float):
         doe = _attn_operand(do)
     dq, dk, dv = torch.empty_like(o), torch.empty_like(o), torch.empty_like(o)
     dsum = torch.empty((B, T), device=o.device, dtype=torch.float32)
-    lib.call("vae_attn_bwd", _p(qe), _p(ke), _p(ve), _p(doe), _p(o), _p(do), _p(lse), B, T, Cc, float(scale), prec,
-             _p(dq), _p(dk), _p(dv), _p(dsum), _stream())
+    # algorithmic: dP, dV, dQ, dK and one recomputation of S = 10 T^2 d; executed: S is recomputed in each of the 3 launches
+    _timed(f"attn_bwd_kernels<{'bf16' if prec == PREC_BF16 else 'f32'}>", 10.0 * B * T * T * Cc, 16.0 * B * T * T * Cc, "vae_attn_bwd",
+           _p(qe), _p(ke), _p(ve), _p(doe), _p(o), _p(do), _p(lse), B, T, Cc, float(scale), prec,
+           _p(dq), _p(dk), _p(dv), _p(dsum), _stream())
     ATTN_CALLS["blockwise_bwd"] += 1
     return dq, dk, dv
 
