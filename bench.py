@@ -173,6 +173,9 @@ def main():
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="launch the ranks, form the process group, all-reduce one number and print it: the multi-rank "
                          "plumbing without touching a GPU (CPU test of the launcher, with --dist-backend gloo)")
+    ap.add_argument("--rendezvous-fail-rank", type=int, default=-1,
+                    help="with --rendezvous-only: this rank exits with status 3 after the all-reduce (CPU test: a failing child "
+                         "rank must make the self-launching parent return non-zero)")
     ap.add_argument("--checkpoint-decoder", action="store_true",
                     help="training.gradient_checkpointing: decoder (BASELINE configs[4], 1024x1024): decoder segments keep only their inputs")
     args = ap.parse_args()
@@ -191,6 +194,8 @@ def main():
             torch.cuda.set_device(local_rank)
             t = t.cuda()
         dist.all_reduce(t)
+        if rank == args.rendezvous_fail_rank:
+            sys.exit(3)
         if rank == 0:
             print(json.dumps({"rendezvous": "ok", "world": dist.get_world_size(), "backend": dist.get_backend(),
                               "allreduce_sum": float(t.item())}))

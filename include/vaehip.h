@@ -190,11 +190,14 @@ int vae_reduce_splits(const float* partial, int32_t nsplit, int64_t n, float* ou
 /* the same for two slabs with one nsplit in ONE launch: the weight-gradient partials and the (small) bias-gradient partials */
 int vae_reduce_splits2(const float* partial, int32_t nsplit, int64_t n, float* out, const float* partial2, int32_t n2, float* out2,
                        void* stream);
-/* ---- GroupNorm (32 groups, eps 1e-6) replaces group_norm fwd/bwd (K2,K7) ---- */
+/* ---- GroupNorm (32 groups, eps 1e-6) replaces group_norm fwd/bwd (K2,K7) ----
+ * x_bf16 != 0: the activation tensor x (and, in the backward, the residual-path gradient `add`) is stored as bf16 -- bf16 mode
+ * keeps conv outputs and the residual stream as bf16, as autocast does for the reference (src/train.py:147-154); statistics,
+ * partial sums and all arithmetic are fp32 either way. */
 /* stage 1: per (b, chunk, group) CENTRED moments ws [B][nchunk][G][2] = (mean, M2 = sum of squared deviations) of chunk
  * `chunk` = pixels [chunk*per, min(HW, (chunk+1)*per)), per = ceil(HW/nchunk): shifted sums, no E[x^2]-mean^2 cancellation
  * (torch's CPU group_norm, which the reference runs on, is a Welford pass; activations with |mean| >> std need it)     */
-int vae_gn_stats_partial(const float* x, int32_t B, int32_t HW, int32_t C, int32_t G,
+int vae_gn_stats_partial(const void* x, int32_t x_bf16, int32_t B, int32_t HW, int32_t C, int32_t G,
                          int32_t nchunk, float* ws, void* stream);
 /* stage 2: Chan's merge of the chunk moments in fp64 -> mean/rstd [B][G] and the fused affine scale/shift [B][C]:
  *   scale = rstd*gamma, shift = beta - mean*rstd*gamma                            */
@@ -202,11 +205,11 @@ int vae_gn_stats_final(const float* ws, int32_t B, int32_t HW, int32_t C, int32_
                        const float* gamma, const float* beta, float eps,
                        float* mean, float* rstd, float* scale, float* shift, void* stream);
 /* y = XF(x) materialised (only for layers with foreign hooks / full maps)        */
-int vae_gn_apply(const float* x, const float* scale, const float* shift, int32_t B, int32_t HW,
+int vae_gn_apply(const void* x, int32_t x_bf16, const float* scale, const float* shift, int32_t B, int32_t HW,
                  int32_t C, int32_t xf, float* y, void* stream);
 /* y16 = bf16(XF(x)): the activation image of a GroupNorm(+SiLU)'d conv input for bf16 mode (C % 8 == 0); the layer's
  * forward and wgrad then read 2 B per element and transform nothing (vae_igemm_args.A16 / vae_wgrad_args.X16)      */
-int vae_gn_apply_bf16(const float* x, const float* scale, const float* shift, int32_t B, int32_t HW,
+int vae_gn_apply_bf16(const void* x, int32_t x_bf16, const float* scale, const float* shift, int32_t B, int32_t HW,
                       int32_t C, int32_t xf, void* y16, void* stream);
 /* 1 when BOTH the forward (vae_igemm_rows) and the weight gradient (vae_wgrad) of the 3x3 stride-1 layer with this
  * forward geometry, Cout and Cin accept a bf16 activation image in bf16 mode (the halo-tile kernels serve them)   */
@@ -216,14 +219,14 @@ int vae_bf16_act_image_ok(const vae_conv_geom* fwd_geom, int32_t Cout, int32_t C
 int vae_bf16_grad_image_ok(const vae_conv_geom* fwd_geom, int32_t Cout, int32_t Cin);
 /* tracker (monitor.py:66): partial sums of |x*scale+shift| per (b,chunk,c);
  * ws [B][nchunk][C]; then vae_track_final                                         */
-int vae_gn_track_partial(const float* x, const float* scale, const float* shift, int32_t B, int32_t HW,
+int vae_gn_track_partial(const void* x, int32_t x_bf16, const float* scale, const float* shift, int32_t B, int32_t HW,
                          int32_t C, int32_t nchunk, float* ws, void* stream);
 /* out[c] = (sum over rows of ws[r][c]) * inv_count ; fixed order                   */
 int vae_track_final(const float* ws, int32_t rows, int32_t C, float inv_count, float* out, void* stream);
 /* GroupNorm(+SiLU) backward.  g = dL/d(XF(gn(x))): fp32, or bf16 when g_bf16 != 0 (bf16 mode stores the dgrad outputs of
  * the halo-tile kernels as bf16, vae_igemm_args.out_bf16).
  * stage 1: ws [B][nchunk][C][2] partial sums of du and du*xhat                     */
-int vae_gn_bwd_partial(const float* x, const void* g, const float* mean, const float* rstd,
+int vae_gn_bwd_partial(const void* x, int32_t x_bf16, const void* g, const float* mean, const float* rstd,
                        const float* gamma, const float* beta, int32_t B, int32_t HW, int32_t C, int32_t G,
                        int32_t nchunk, int32_t silu, int32_t g_bf16, float* ws, void* stream);
 /* stage 2: dgamma/dbeta [C] (written, not accumulated) and coefficients
@@ -234,8 +237,8 @@ int vae_gn_bwd_final(const float* ws, const float* rstd, const float* gamma, int
 /* stage 3: dx = du*rstd*gamma - xhat*coef0 - coef1 (+ add), written as fp32 (dx) and / or as bf16 (dx16); at least one.
  * A gradient that only feeds convolutions (dL/dh of a resnet) needs the bf16 copy alone -- the bf16 kernels would round it
  * at the same point; one that also carries the residual stream gets both.                                              */
-int vae_gn_bwd_apply(const float* x, const void* g, const float* mean, const float* rstd,
-                     const float* gamma, const float* beta, const float* coef, const float* add,
+int vae_gn_bwd_apply(const void* x, int32_t x_bf16, const void* g, const float* mean, const float* rstd,
+                     const float* gamma, const float* beta, const float* coef, const void* add,
                      int32_t B, int32_t HW, int32_t C, int32_t G, int32_t silu, int32_t g_bf16, float* dx, void* dx16, void* stream);
 
 /* ---- attention softmax (K3) ---- */

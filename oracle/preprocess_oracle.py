@@ -18,9 +18,17 @@ PRECISION_BITS = 32 - 8 - 2
 
 def resized_size(w: int, h: int, resolution: int):
     """Resize(int): the shorter side becomes `resolution`, the other keeps the aspect ratio (data_utils.py:25;
-    this repo's src/data_utils.py:get_transform computes the same)."""
-    s = resolution / min(w, h)
-    return max(resolution, int(round(w * s))), max(resolution, int(round(h * s)))
+    this repo's src/data_utils.py:get_transform computes the same).
+    Restated from torchvision's published `_compute_resized_output_size` (torchvision is not installed: parity with it is
+    unpinned): new_short = resolution, new_long = int(resolution * long / short) -- truncation."""
+    if w <= h:
+        return resolution, int(resolution * h / w)
+    return int(resolution * w / h), resolution
+
+
+def crop_offset(size: int, resolution: int) -> int:
+    """torchvision CenterCrop: crop_top = int(round((image_height - crop_height) / 2.0)) (Python round: half to even)"""
+    return int(round((size - resolution) / 2.0))
 
 
 def coeffs(in_size: int, out_size: int):
@@ -74,7 +82,7 @@ def transform_u8(img: np.ndarray, resolution: int) -> np.ndarray:
         bx, kx = coeffs(w, nw)
         by, ky = coeffs(h, nh)
         img = _pass(_pass(img, bx, kx, 1), by, ky, 0)
-    left, top = (nw - resolution) // 2, (nh - resolution) // 2
+    left, top = crop_offset(nw, resolution), crop_offset(nh, resolution)
     return img[top:top + resolution, left:left + resolution]
 
 

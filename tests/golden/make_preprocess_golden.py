@@ -15,6 +15,8 @@ from data_utils import get_transform  # noqa: E402
 
 CASES = [  # (height, width, channels, resolution)
     (30, 40, 3, 16), (375, 500, 3, 64), (20, 20, 3, 32), (97, 61, 3, 32), (64, 64, 3, 64), (50, 70, 1, 32), (33, 100, 3, 48),
+    (427, 640, 3, 256),  # long side 383.7 -> 383 (torchvision truncates), margin 127 -> offset 64 (63.5 rounds to even)
+    (41, 30, 3, 16),     # portrait: 16 x 21 (21.87 truncated), margin 5 -> offset 2 (2.5 rounds to even, not 3)
 ]
 
 

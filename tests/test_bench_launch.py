@@ -20,6 +20,20 @@ def test_bench_self_launches_its_ranks():
     assert out == {"rendezvous": "ok", "world": 2, "backend": "gloo", "allreduce_sum": 3.0}
 
 
+def test_a_failing_child_rank_fails_the_bench():
+    """rank 1 exits non-zero after the collective: the self-launching parent must pass a non-zero status on (the driver reads
+    it), and a rank other than 0 never prints a result line"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--rendezvous-only",
+                        "--rendezvous-fail-rank", "1"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0, r.stdout[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) <= 1 and all(json.loads(ln).get("rendezvous") == "ok" for ln in lines), r.stdout  # rank 0's line at most
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--rendezvous-only",
+                        "--rendezvous-fail-rank", "0"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")], r.stdout  # rank 1 prints nothing
+
+
 def test_bench_rejects_a_world_that_does_not_match():
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-only"],

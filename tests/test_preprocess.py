@@ -45,6 +45,13 @@ def test_host_coefficient_tables_match_the_restatement():
         assert np.array_equal(b3, b[lo:lo + n]) and np.array_equal(k3, k[lo:lo + n])
         assert int(k.sum(axis=1).min()) >= (1 << 22) - k.shape[1] and int(k.sum(axis=1).max()) <= (1 << 22) + k.shape[1]
     assert resized_size(500, 375, 64) == po.resized_size(500, 375, 64) == (85, 64)
+    # torchvision's geometry (reference src/data_utils.py:25-26): Resize(int) TRUNCATES the long side, CenterCrop rounds the half
+    # margin half-to-even -- known answers worked by hand from torchvision's published formulas (parity with torchvision itself
+    # is unpinned: not installed)
+    from vaehip.preprocess import crop_offset
+    assert resized_size(640, 427, 256) == po.resized_size(640, 427, 256) == (383, 256)   # 383.7 -> 383, not 384
+    assert resized_size(30, 41, 16) == po.resized_size(30, 41, 16) == (16, 21)           # portrait: 21.87 -> 21
+    assert [crop_offset(n, 16) for n in (16, 17, 19, 21, 23)] == [po.crop_offset(n, 16) for n in (16, 17, 19, 21, 23)] == [0, 0, 2, 2, 4]
 
 
 def test_raw_batch_loader_plumbing(tmp_path):

@@ -1,5 +1,5 @@
 """Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) -> profiles/<name>.json.
-usage: python tools/hbm_traffic.py <dir_with_fetch_pass> <dir_with_write_pass> <out.json>
+usage: python tools/hbm_traffic.py <dir_with_fetch_pass> <dir_with_write_pass> <out.json> [commit]
 FETCH_SIZE/WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reads half the bytes a 16-B/lane coalesced stream fetches
 (MI355X_MICROARCH.md, HBM section), hence the x2 on the read side."""
 import collections
@@ -32,6 +32,7 @@ def main():
     tot = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in out.values())
     json.dump({"doc": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `bench.py --steps 1 --warmup 1` (2 steps incl. "
                       "warm-up); FETCH_SIZE x2 (gfx950 correction for 16-B/lane coalesced reads), KB->bytes",
+               "commit": sys.argv[4] if len(sys.argv) > 4 else "unrecorded",
                "total_hbm_bytes_both_steps": tot, "kernels": out}, open(sys.argv[3], "w"), indent=1)
     print(f"total {tot / 2e9:.1f} GB per step")
 

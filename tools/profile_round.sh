@@ -1,8 +1,8 @@
 #!/bin/bash
 # Round profile set (GPU box): rocprofv3 kernel stats of the fp32 and bf16 bench, HBM-traffic PMC passes (separate runs,
-# FETCH_SIZE / WRITE_SIZE only), the dead-weight scan.  usage: bash tools/profile_round.sh r02
+# FETCH_SIZE / WRITE_SIZE only), the dead-weight scan.  usage: bash tools/profile_round.sh r03 <commit>
 set -x
-R=$GRAFT_REPO_ROOT; TAG=${1:-r02}; O=$R/gpurun_out/$TAG; mkdir -p $O
+R=$GRAFT_REPO_ROOT; TAG=${1:-r03}; COMMIT=${2:-unrecorded}; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_f32 -o k -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-profile > $O/stats_f32.json 2> $O/stats_f32.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_bf16 -o k -- python3 $R/bench.py --dtype bf16 --steps 4 --warmup 2 --no-cpu-baseline --no-profile > $O/stats_bf16.json 2> $O/stats_bf16.err
@@ -13,8 +13,8 @@ for P in f32 bf16; do
   done
 done
 cd $R
-python3 tools/hbm_traffic.py $O/pmc_f32_FETCH_SIZE $O/pmc_f32_WRITE_SIZE $O/hbm_traffic.json
-python3 tools/hbm_traffic.py $O/pmc_bf16_FETCH_SIZE $O/pmc_bf16_WRITE_SIZE $O/hbm_traffic_bf16.json
+python3 tools/hbm_traffic.py $O/pmc_f32_FETCH_SIZE $O/pmc_f32_WRITE_SIZE $O/hbm_traffic_f32.json $COMMIT
+python3 tools/hbm_traffic.py $O/pmc_bf16_FETCH_SIZE $O/pmc_bf16_WRITE_SIZE $O/hbm_traffic_bf16.json $COMMIT
 # keep the merged-back volume small: the raw counter CSVs are large
 rm -rf $O/pmc_*_SIZE/*/ 2>/dev/null; find $O -name "*_kernel_trace.csv" -size +20M -delete
 ls -la $O

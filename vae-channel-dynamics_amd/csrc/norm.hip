@@ -1,4 +1,6 @@
-// GroupNorm(32 groups) statistics, tracker reduction and backward for NHWC fp32.
+// GroupNorm(32 groups) statistics, tracker reduction and backward for NHWC activations stored as fp32 or as bf16 (x_bf16:
+// bf16 mode keeps conv outputs and the residual stream as bf16, as autocast does for the reference; statistics, sums and
+// the arithmetic stay fp32).
 // All kernels are HBM-bound streaming passes: lanes run across channels (float4 per lane,
 // fully coalesced rows), each workgroup owns one pixel chunk of one image, and every
 // cross-workgroup reduction is "per-workgroup partial + fixed-order final pass" so results
@@ -28,6 +30,15 @@ __device__ __forceinline__ uint2 pack4_bf16(f32x4 v) {
   return __builtin_bit_cast(uint2, h);
 }
 
+// activation tensors: element quad `idx4` of a tensor stored as fp32 or bf16
+template <bool BF>
+__device__ __forceinline__ f32x4 load4x(const void* base, int64_t idx4) { return load4g<BF>(base, idx4); }
+template <bool BF>
+__device__ __forceinline__ void store4x(void* base, int64_t idx4, f32x4 v) {
+  if (!BF) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + idx4 * 4) = v;
+  else *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base) + idx4 * 4) = pack4_bf16(v);
+}
+
 // layout helper: 256 threads = PR pixel rows x Q float4 lanes (Q = C/4)
 struct Lay {
   int Q, PR, cq, pr;
@@ -41,18 +52,19 @@ __device__ __forceinline__ Lay make_lay(int C) {
   return l;
 }
 
-__global__ __launch_bounds__(256) void gn_stats_partial_kernel(const float* __restrict__ x, int HW, int C, int G,
+template <bool XBF>
+__global__ __launch_bounds__(256) void gn_stats_partial_kernel(const void* __restrict__ x, int HW, int C, int G,
                                                                int nchunk, float* __restrict__ ws) {
   __shared__ float red[3][256];
   const Lay l = make_lay(C);
   const int chunk = blockIdx.x, b = blockIdx.y;
   const int per = (HW + nchunk - 1) / nchunk;
   const int p0 = chunk * per, p1 = min(HW, p0 + per);
-  const float* xb = x + (int64_t)b * HW * C;
+  const int64_t xb4 = (int64_t)b * HW * l.Q;
   // shifted sums around the thread's first value (no cancellation), then centred moments, merged over the group's threads
   float pv = 0.f, s1 = 0.f, s2 = 0.f, cnt = 0.f;
   for (int pix = p0 + l.pr; pix < p1; pix += l.PR) {
-    f32x4 v = *reinterpret_cast<const f32x4*>(xb + (int64_t)pix * C + l.cq * 4);
+    f32x4 v = load4x<XBF>(x, xb4 + (int64_t)pix * l.Q + l.cq);
     if (cnt == 0.f) pv = v[0];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -156,7 +168,8 @@ __global__ __launch_bounds__(256) void gn_stats_final_kernel(const float* __rest
   }
 }
 
-__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+template <bool XBF>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const void* __restrict__ x, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, int64_t n4, int HWQ, int Q,
                                                        int C, int xf, float* __restrict__ y) {
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -164,7 +177,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
   for (; i < n4; i += stride) {
     const int b = (int)(i / HWQ);
     const int c = (int)(i % Q) * 4;
-    f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+    f32x4 v = load4x<XBF>(x, i);
     f32x4 sc = *reinterpret_cast<const f32x4*>(scale + (int64_t)b * C + c);
     f32x4 sh = *reinterpret_cast<const f32x4*>(shift + (int64_t)b * C + c);
     f32x4 o;
@@ -178,7 +191,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
 }
 
 // same transform, output rounded to bf16 (the activation image the bf16 conv / wgrad kernels read): 8 elements per thread
-__global__ __launch_bounds__(256) void gn_apply_bf16_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+template <bool XBF>
+__global__ __launch_bounds__(256) void gn_apply_bf16_kernel(const void* __restrict__ x, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, int64_t n8, int HWQ, int Q,
                                                             int C, int xf, unsigned short* __restrict__ y) {
   typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -190,7 +204,7 @@ __global__ __launch_bounds__(256) void gn_apply_bf16_kernel(const float* __restr
     bf16x8_t h;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 8 + half * 4);
+      const f32x4 v = load4x<XBF>(x, i * 2 + half);
       const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + (int64_t)b * C + c + half * 4);
       const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + (int64_t)b * C + c + half * 4);
 #pragma unroll
@@ -203,7 +217,8 @@ __global__ __launch_bounds__(256) void gn_apply_bf16_kernel(const float* __restr
   }
 }
 
-__global__ __launch_bounds__(256) void gn_track_partial_kernel(const float* __restrict__ x,
+template <bool XBF>
+__global__ __launch_bounds__(256) void gn_track_partial_kernel(const void* __restrict__ x,
                                                                const float* __restrict__ scale,
                                                                const float* __restrict__ shift, int HW, int C,
                                                                int nchunk, float* __restrict__ ws) {
@@ -212,12 +227,12 @@ __global__ __launch_bounds__(256) void gn_track_partial_kernel(const float* __re
   const int chunk = blockIdx.x, b = blockIdx.y;
   const int per = (HW + nchunk - 1) / nchunk;
   const int p0 = chunk * per, p1 = min(HW, p0 + per);
-  const float* xb = x + (int64_t)b * HW * C;
+  const int64_t xb4 = (int64_t)b * HW * l.Q;
   const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + (int64_t)b * C + l.cq * 4);
   const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + (int64_t)b * C + l.cq * 4);
   f32x4 s = {0, 0, 0, 0};
   for (int pix = p0 + l.pr; pix < p1; pix += l.PR) {
-    f32x4 v = *reinterpret_cast<const f32x4*>(xb + (int64_t)pix * C + l.cq * 4);
+    f32x4 v = load4x<XBF>(x, xb4 + (int64_t)pix * l.Q + l.cq);
 #pragma unroll
     for (int e = 0; e < 4; ++e) s[e] += fabsf(v[e] * sc[e] + sh[e]);
   }
@@ -254,8 +269,8 @@ __global__ __launch_bounds__(256) void track_final_kernel(const float* __restric
   if (threadIdx.x < 4 && c0 + (int)threadIdx.x < C) out[c0 + threadIdx.x] = (float)(red[0][threadIdx.x] * (double)inv_count);
 }
 
-template <bool SILU, bool GBF>
-__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __restrict__ x, const void* __restrict__ g,
+template <bool SILU, bool GBF, bool XBF>
+__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const void* __restrict__ x, const void* __restrict__ g,
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ rstd,
                                                              const float* __restrict__ gamma,
@@ -270,11 +285,10 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __rest
   const float mu = mean[b * G + grp], rs = rstd[b * G + grp];
   const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
   const f32x4 be = *reinterpret_cast<const f32x4*>(beta + c);
-  const float* xb = x + (int64_t)b * HW * C;
   const int64_t gb4 = (int64_t)b * HW * (C / 4);
   f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
   for (int pix = p0 + l.pr; pix < p1; pix += l.PR) {
-    f32x4 v = *reinterpret_cast<const f32x4*>(xb + (int64_t)pix * C + c);
+    f32x4 v = load4x<XBF>(x, gb4 + (int64_t)pix * (C / 4) + l.cq);
     f32x4 gv = load4g<GBF>(g, gb4 + (int64_t)pix * (C / 4) + l.cq);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -370,14 +384,14 @@ __global__ __launch_bounds__(256) void gn_bwd_final_kernel(const float* __restri
     coef[((int64_t)b * G + g) * 2 + 1] = (float)(r * s1 / n);
   }
 }
-template <bool SILU, bool GBF>
-__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, const void* __restrict__ g,
+template <bool SILU, bool GBF, bool XBF>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const void* __restrict__ x, const void* __restrict__ g,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta,
                                                            const float* __restrict__ coef,
-                                                           const float* __restrict__ add, int64_t n4, int HWQ, int Q,
+                                                           const void* __restrict__ add, int64_t n4, int HWQ, int Q,
                                                            int C, int G, float* __restrict__ dx,
                                                            unsigned short* __restrict__ dx16) {
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -389,12 +403,12 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
     const int grp = c / cpg;
     const float mu = mean[b * G + grp], rs = rstd[b * G + grp];
     const float k0 = coef[((int64_t)b * G + grp) * 2 + 0], k1 = coef[((int64_t)b * G + grp) * 2 + 1];
-    f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+    f32x4 v = load4x<XBF>(x, i);
     f32x4 gv = load4g<GBF>(g, i);
     f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
     f32x4 be = *reinterpret_cast<const f32x4*>(beta + c);
     f32x4 o;
-    if (add) o = *reinterpret_cast<const f32x4*>(add + i * 4);
+    if (add) o = load4x<XBF>(add, i);  // (the residual-path gradient is stored like x)
     else o = f32x4{0, 0, 0, 0};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -423,11 +437,12 @@ inline int ew_blocks(int64_t n) {
 
 }  // namespace
 
-extern "C" int vae_gn_stats_partial(const float* x, int32_t B, int32_t HW, int32_t C, int32_t G, int32_t nchunk,
+extern "C" int vae_gn_stats_partial(const void* x, int32_t x_bf16, int32_t B, int32_t HW, int32_t C, int32_t G, int32_t nchunk,
                                     float* ws, void* stream) {
   if (int e = check_gn("gn_stats_partial", B, HW, C, G, nchunk)) return e;
   VAE_CHECK(x && ws && aligned16(x), "gn_stats_partial: bad pointers");
-  hipLaunchKernelGGL(gn_stats_partial_kernel, dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream, x, HW, C, G, nchunk, ws);
+  if (x_bf16) hipLaunchKernelGGL(gn_stats_partial_kernel<true>, dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream, x, HW, C, G, nchunk, ws);
+  else hipLaunchKernelGGL(gn_stats_partial_kernel<false>, dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream, x, HW, C, G, nchunk, ws);
   VAE_LAUNCH_CHECK("gn_stats_partial");
   return VAE_OK;
 }
@@ -443,38 +458,40 @@ extern "C" int vae_gn_stats_final(const float* ws, int32_t B, int32_t HW, int32_
   return VAE_OK;
 }
 
-extern "C" int vae_gn_apply(const float* x, const float* scale, const float* shift, int32_t B, int32_t HW, int32_t C,
+extern "C" int vae_gn_apply(const void* x, int32_t x_bf16, const float* scale, const float* shift, int32_t B, int32_t HW, int32_t C,
                             int32_t xf, float* y, void* stream) {
   VAE_CHECK(x && scale && shift && y && B > 0 && HW > 0 && C > 0 && C % 4 == 0, "gn_apply: bad args");
   VAE_CHECK(aligned16(x) && aligned16(y) && aligned16(scale) && aligned16(shift), "gn_apply: unaligned");
   const int Q = C / 4;
   const int64_t n4 = (int64_t)B * HW * Q;
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, n4, HW * Q, Q,
-                     C, xf, y);
+  if (x_bf16) hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, n4, HW * Q, Q, C, xf, y);
+  else hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, n4, HW * Q, Q, C, xf, y);
   VAE_LAUNCH_CHECK("gn_apply");
   return VAE_OK;
 }
 
-extern "C" int vae_gn_apply_bf16(const float* x, const float* scale, const float* shift, int32_t B, int32_t HW, int32_t C,
+extern "C" int vae_gn_apply_bf16(const void* x, int32_t x_bf16, const float* scale, const float* shift, int32_t B, int32_t HW, int32_t C,
                                  int32_t xf, void* y16, void* stream) {
   VAE_CHECK(x && scale && shift && y16 && B > 0 && HW > 0 && C > 0 && C % 8 == 0, "gn_apply_bf16: bad args (C %% 8 == 0)");
   VAE_CHECK(aligned16(x) && aligned16(y16) && aligned16(scale) && aligned16(shift), "gn_apply_bf16: unaligned");
   const int Q = C / 8;
   const int64_t n8 = (int64_t)B * HW * Q;
-  hipLaunchKernelGGL(gn_apply_bf16_kernel, dim3(ew_blocks(n8)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, n8,
-                     HW * Q, Q, C, xf, reinterpret_cast<unsigned short*>(y16));
+  if (x_bf16) hipLaunchKernelGGL(gn_apply_bf16_kernel<true>, dim3(ew_blocks(n8)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, n8,
+                                 HW * Q, Q, C, xf, reinterpret_cast<unsigned short*>(y16));
+  else hipLaunchKernelGGL(gn_apply_bf16_kernel<false>, dim3(ew_blocks(n8)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, n8,
+                          HW * Q, Q, C, xf, reinterpret_cast<unsigned short*>(y16));
   VAE_LAUNCH_CHECK("gn_apply_bf16");
   return VAE_OK;
 }
 
-extern "C" int vae_gn_track_partial(const float* x, const float* scale, const float* shift, int32_t B, int32_t HW,
+extern "C" int vae_gn_track_partial(const void* x, int32_t x_bf16, const float* scale, const float* shift, int32_t B, int32_t HW,
                                     int32_t C, int32_t nchunk, float* ws, void* stream) {
   VAE_CHECK(B > 0 && HW > 0 && nchunk > 0 && nchunk <= 65535 && B <= 65535, "gn_track_partial: bad sizes");
   VAE_CHECK(C > 0 && C % 4 == 0 && (C / 4) <= 256 && 256 % (C / 4) == 0, "gn_track_partial: C=%d unsupported", C);
   VAE_CHECK(x && scale && shift && ws && aligned16(x) && aligned16(scale) && aligned16(shift) && aligned16(ws),
             "gn_track_partial: bad pointers");
-  hipLaunchKernelGGL(gn_track_partial_kernel, dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream, x, scale, shift, HW, C,
-                     nchunk, ws);
+  if (x_bf16) hipLaunchKernelGGL(gn_track_partial_kernel<true>, dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream, x, scale, shift, HW, C, nchunk, ws);
+  else hipLaunchKernelGGL(gn_track_partial_kernel<false>, dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream, x, scale, shift, HW, C, nchunk, ws);
   VAE_LAUNCH_CHECK("gn_track_partial");
   return VAE_OK;
 }
@@ -486,15 +503,17 @@ extern "C" int vae_track_final(const float* ws, int32_t rows, int32_t C, float i
   return VAE_OK;
 }
 
-extern "C" int vae_gn_bwd_partial(const float* x, const void* g, const float* mean, const float* rstd,
+extern "C" int vae_gn_bwd_partial(const void* x, int32_t x_bf16, const void* g, const float* mean, const float* rstd,
                                   const float* gamma, const float* beta, int32_t B, int32_t HW, int32_t C, int32_t G,
                                   int32_t nchunk, int32_t silu, int32_t g_bf16, float* ws, void* stream) {
   if (int e = check_gn("gn_bwd_partial", B, HW, C, G, nchunk)) return e;
   VAE_CHECK(x && g && mean && rstd && gamma && beta && ws, "gn_bwd_partial: null pointer");
   VAE_CHECK(aligned16(x) && aligned16(g) && aligned16(gamma) && aligned16(beta), "gn_bwd_partial: unaligned");
-#define GNP(S, BF) hipLaunchKernelGGL((gn_bwd_partial_kernel<S, BF>), dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream, x, g, mean, rstd, gamma, beta, HW, C, G, nchunk, ws)
-  if (silu) { if (g_bf16) GNP(true, true); else GNP(true, false); }
-  else { if (g_bf16) GNP(false, true); else GNP(false, false); }
+#define GNP(S, BF, XB) hipLaunchKernelGGL((gn_bwd_partial_kernel<S, BF, XB>), dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream, x, g, mean, rstd, gamma, beta, HW, C, G, nchunk, ws)
+#define GNP2(S, BF) do { if (x_bf16) GNP(S, BF, true); else GNP(S, BF, false); } while (0)
+  if (silu) { if (g_bf16) GNP2(true, true); else GNP2(true, false); }
+  else { if (g_bf16) GNP2(false, true); else GNP2(false, false); }
+#undef GNP2
 #undef GNP
   VAE_LAUNCH_CHECK("gn_bwd_partial");
   return VAE_OK;
@@ -511,8 +530,8 @@ extern "C" int vae_gn_bwd_final(const float* ws, const float* rstd, const float*
   return VAE_OK;
 }
 
-extern "C" int vae_gn_bwd_apply(const float* x, const void* g, const float* mean, const float* rstd,
-                                const float* gamma, const float* beta, const float* coef, const float* add, int32_t B,
+extern "C" int vae_gn_bwd_apply(const void* x, int32_t x_bf16, const void* g, const float* mean, const float* rstd,
+                                const float* gamma, const float* beta, const float* coef, const void* add, int32_t B,
                                 int32_t HW, int32_t C, int32_t G, int32_t silu, int32_t g_bf16, float* dx, void* dx16, void* stream) {
   if (int e = check_gn("gn_bwd_apply", B, HW, C, G, 1)) return e;
   VAE_CHECK(x && g && mean && rstd && gamma && beta && coef && (dx || dx16), "gn_bwd_apply: null pointer");
@@ -521,9 +540,11 @@ extern "C" int vae_gn_bwd_apply(const float* x, const void* g, const float* mean
             "gn_bwd_apply: unaligned");
   const int Q = C / 4;
   const int64_t n4 = (int64_t)B * HW * Q;
-#define GNA(S, BF) hipLaunchKernelGGL((gn_bwd_apply_kernel<S, BF>), dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, x, g, mean, rstd, gamma, beta, coef, add, n4, HW * Q, Q, C, G, dx, (unsigned short*)dx16)
-  if (silu) { if (g_bf16) GNA(true, true); else GNA(true, false); }
-  else { if (g_bf16) GNA(false, true); else GNA(false, false); }
+#define GNA(S, BF, XB) hipLaunchKernelGGL((gn_bwd_apply_kernel<S, BF, XB>), dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, x, g, mean, rstd, gamma, beta, coef, add, n4, HW * Q, Q, C, G, dx, (unsigned short*)dx16)
+#define GNA2(S, BF) do { if (x_bf16) GNA(S, BF, true); else GNA(S, BF, false); } while (0)
+  if (silu) { if (g_bf16) GNA2(true, true); else GNA2(true, false); }
+  else { if (g_bf16) GNA2(false, true); else GNA2(false, false); }
+#undef GNA2
 #undef GNA
   VAE_LAUNCH_CHECK("gn_bwd_apply");
   return VAE_OK;

@@ -29,11 +29,13 @@ def get_transform(resolution: int):
 
     def tf(img) -> torch.Tensor:
         w, h = img.size
-        s = resolution / min(w, h)
-        nw, nh = max(resolution, int(round(w * s))), max(resolution, int(round(h * s)))
+        # torchvision's Resize(int) truncates the long side; CenterCrop rounds the half margin (half to even)
+        short, long = (w, h) if w <= h else (h, w)
+        new_long = int(resolution * long / short)
+        nw, nh = (resolution, new_long) if w <= h else (new_long, resolution)
         if (nw, nh) != (w, h):
             img = img.resize((nw, nh), Image.BILINEAR)
-        left, top = (nw - resolution) // 2, (nh - resolution) // 2
+        left, top = int(round((nw - resolution) / 2.0)), int(round((nh - resolution) / 2.0))
         img = img.crop((left, top, left + resolution, top + resolution))
         if img.mode != "RGB":
             img = img.convert("RGB")

@@ -68,16 +68,16 @@ SIGNATURES = {
     "vae_wgrad_kernel_name": [C.POINTER(WgradArgs), C.c_char_p, i32],
     "vae_reduce_splits": [vp, i32, i64, vp, vp],
     "vae_reduce_splits2": [vp, i32, i64, vp, vp, i32, vp, vp],
-    "vae_gn_stats_partial": [vp, i32, i32, i32, i32, i32, vp, vp],
+    "vae_gn_stats_partial": [vp, i32, i32, i32, i32, i32, i32, vp, vp],
     "vae_gn_stats_final": [vp, i32, i32, i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp],
-    "vae_gn_apply": [vp, vp, vp, i32, i32, i32, i32, vp, vp],
-    "vae_gn_apply_bf16": [vp, vp, vp, i32, i32, i32, i32, vp, vp],
+    "vae_gn_apply": [vp, i32, vp, vp, i32, i32, i32, i32, vp, vp],
+    "vae_gn_apply_bf16": [vp, i32, vp, vp, i32, i32, i32, i32, vp, vp],
     "vae_bf16_act_image_ok": [C.POINTER(ConvGeom), i32, i32],
-    "vae_gn_track_partial": [vp, vp, vp, i32, i32, i32, i32, vp, vp],
+    "vae_gn_track_partial": [vp, i32, vp, vp, i32, i32, i32, i32, vp, vp],
     "vae_track_final": [vp, i32, i32, f32, vp, vp],
-    "vae_gn_bwd_partial": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp],
+    "vae_gn_bwd_partial": [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp],
     "vae_gn_bwd_final": [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp],
-    "vae_gn_bwd_apply": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp],
+    "vae_gn_bwd_apply": [vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp],
     "vae_attn_supported": [i32, i32],
     "vae_attn_fwd": [vp, vp, vp, i32, i32, i32, f32, i32, vp, vp, vp],
     "vae_attn_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp],

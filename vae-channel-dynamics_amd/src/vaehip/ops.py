@@ -157,6 +157,11 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _b16(t: Optional[torch.Tensor]) -> int:
+    """1 when the tensor is stored as bf16 (the *_bf16 flags of the C ABI)"""
+    return 1 if (t is not None and t.dtype == torch.bfloat16) else 0
+
+
 def _chk(t: torch.Tensor, name: str):
     if not (t.is_cuda and t.dtype == torch.float32):
         raise ValueError(f"{name}: expected a float32 CUDA tensor, got {t.dtype} on {t.device}")
@@ -261,7 +266,7 @@ def gn_apply_bf16(x: torch.Tensor, st: "Stats", xf: int) -> torch.Tensor:
     """bf16(XF(x)) as a [B,H,W,C] bfloat16 tensor: the activation image conv_fwd(a16=) / conv_wgrad(x16=) read."""
     B, H, W, Cc = x.shape
     y = torch.empty((B, H, W, Cc), device=x.device, dtype=torch.bfloat16)
-    lib.call("vae_gn_apply_bf16", _p(x), _p(st.scale), _p(st.shift), B, H * W, Cc, xf, _p(y), _stream())
+    lib.call("vae_gn_apply_bf16", _p(x), _b16(x), _p(st.scale), _p(st.shift), B, H * W, Cc, xf, _p(y), _stream())
     return y
 
 
@@ -676,7 +681,7 @@ def gn_stats(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, G: int = 
     else:
         nch = _gn_nchunk(B, HW, Cc)
         ws = torch.empty((B, nch, G, 2), device=dev, dtype=torch.float32)
-        lib.call("vae_gn_stats_partial", _p(x), B, HW, Cc, G, nch, _p(ws), _stream())
+        lib.call("vae_gn_stats_partial", _p(x), _b16(x), B, HW, Cc, G, nch, _p(ws), _stream())
     mean = torch.empty((B, G), device=dev, dtype=torch.float32)
     rstd = torch.empty((B, G), device=dev, dtype=torch.float32)
     scale = torch.empty((B, Cc), device=dev, dtype=torch.float32)
@@ -688,8 +693,8 @@ def gn_stats(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, G: int = 
 
 def gn_apply(x: torch.Tensor, st: Stats, xf: int) -> torch.Tensor:
     B, H, W, Cc = x.shape
-    y = torch.empty_like(x)
-    lib.call("vae_gn_apply", _p(x), _p(st.scale), _p(st.shift), B, H * W, Cc, xf, _p(y), _stream())
+    y = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    lib.call("vae_gn_apply", _p(x), _b16(x), _p(st.scale), _p(st.shift), B, H * W, Cc, xf, _p(y), _stream())
     return y
 
 
@@ -700,7 +705,7 @@ def gn_track(x: torch.Tensor, st: Stats) -> torch.Tensor:
     nch = _gn_nchunk(B, HW, Cc)
     ws = torch.empty((B * nch, Cc), device=x.device, dtype=torch.float32)
     out = torch.empty((Cc,), device=x.device, dtype=torch.float32)
-    lib.call("vae_gn_track_partial", _p(x), _p(st.scale), _p(st.shift), B, HW, Cc, nch, _p(ws), _stream())
+    lib.call("vae_gn_track_partial", _p(x), _b16(x), _p(st.scale), _p(st.shift), B, HW, Cc, nch, _p(ws), _stream())
     lib.call("vae_track_final", _p(ws), B * nch, Cc, 1.0 / float(B * HW), _p(out), _stream())
     return out
 
@@ -735,10 +740,10 @@ def gn_bwd(x: torch.Tensor, g: torch.Tensor, st: Stats, gamma: torch.Tensor, bet
     dx = torch.empty_like(x) if want32 else None
     dx16 = torch.empty(x.shape, device=dev, dtype=torch.bfloat16) if want16 else None
     s = _stream()
-    lib.call("vae_gn_bwd_partial", _p(x), _p(g), _p(st.mean), _p(st.rstd), _p(gamma), _p(beta), B, HW, Cc, G, nch,
+    lib.call("vae_gn_bwd_partial", _p(x), _b16(x), _p(g), _p(st.mean), _p(st.rstd), _p(gamma), _p(beta), B, HW, Cc, G, nch,
              int(silu), int(g16), _p(ws), s)
     lib.call("vae_gn_bwd_final", _p(ws), _p(st.rstd), _p(gamma), B, HW, Cc, G, nch, _p(dgamma), _p(dbeta), _p(coef), s)
-    lib.call("vae_gn_bwd_apply", _p(x), _p(g), _p(st.mean), _p(st.rstd), _p(gamma), _p(beta), _p(coef), _p(add), B, HW,
+    lib.call("vae_gn_bwd_apply", _p(x), _b16(x), _p(g), _p(st.mean), _p(st.rstd), _p(gamma), _p(beta), _p(coef), _p(add), B, HW,
              Cc, G, int(silu), int(g16), _p(dx), _p(dx16), s)
     if dx is None:
         return dx16

@@ -19,9 +19,17 @@ PRECISION_BITS = 32 - 8 - 2  # Pillow Resample.c
 
 
 def resized_size(w: int, h: int, resolution: int) -> Tuple[int, int]:
-    """Resize(int): shorter side -> resolution (same rounding as data_utils.get_transform)"""
-    s = resolution / min(w, h)
-    return max(resolution, int(round(w * s))), max(resolution, int(round(h * s)))
+    """torchvision's Resize(int) (reference src/data_utils.py:25): the shorter side becomes `resolution`, the longer one
+    int(resolution * long / short) -- TRUNCATED, not rounded (640x427 -> 383x256).  -> (new_w, new_h)"""
+    short, long = (w, h) if w <= h else (h, w)
+    new_long = int(resolution * long / short)
+    return (resolution, new_long) if w <= h else (new_long, resolution)
+
+
+def crop_offset(size: int, resolution: int) -> int:
+    """torchvision's CenterCrop (reference src/data_utils.py:26): int(round((size - crop) / 2.0)) with Python's
+    round-half-to-even (margin 1 -> 0, margin 3 -> 2, margin 5 -> 2)"""
+    return int(round((size - resolution) / 2.0))
 
 
 def bilinear_coeffs(in_size: int, out_size: int, first: int, count: int):
@@ -61,7 +69,7 @@ class GpuPreprocessor:
         if key not in self._tables:
             R = self.res
             nw, nh = resized_size(w, h, R)
-            left, top = (nw - R) // 2, (nh - R) // 2
+            left, top = crop_offset(nw, R), crop_offset(nh, R)
             bx, kx = bilinear_coeffs(w, nw, left, R)
             by, ky = bilinear_coeffs(h, nh, top, R)
             row0 = int(by[:, 0].min())
