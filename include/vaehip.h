@@ -48,9 +48,12 @@ int vae_get_option(const char* name);
 #define VAE_XF_AFFINE 1      /* x*scale[b][c]+shift[b][c]            (GroupNorm, no activation) */
 #define VAE_XF_AFFINE_SILU 2 /* silu(x*scale[b][c]+shift[b][c])      (GroupNorm + SiLU)         */
 
-/* arithmetic of the contraction.  Tensors in HBM are fp32 in both modes (fp32 master weights / statistics);
- * BF16 rounds the operands to bf16 while staging them in LDS and multiplies on v_mfma_f32_32x32x16_bf16 with
- * fp32 accumulation (`training.mixed_precision: bf16`).  Shapes without a bf16 kernel run the fp32 one.   */
+/* arithmetic of the contraction.  BF16 multiplies bf16 operands on v_mfma_f32_32x32x16_bf16 with fp32 accumulation
+ * (`training.mixed_precision: bf16`); parameters, GroupNorm statistics, loss and optimizer stay fp32 in both modes.
+ * STORAGE of the activation / gradient tensors is a separate, per-tensor property in bf16 mode: every operand is fp32
+ * unless the argument block says otherwise (A16 / a_bf16 / out_bf16 / res_bf16, X16 / dY16 / x_bf16 / y_bf16, x_bf16 of the
+ * GroupNorm entry points) -- the host keeps conv outputs, the residual stream and their gradients as bf16, which is what
+ * autocast does for the reference (src/train.py:147-154).  Shapes without a bf16 kernel run the fp32 one (fp32 storage). */
 #define VAE_PREC_F32 0
 #define VAE_PREC_BF16 1
 
@@ -110,8 +113,13 @@ typedef struct vae_igemm_args {
                           * vae_gn_stats_partial writes, so vae_gn_stats_final finishes it; saves re-reading the output */
   const float* Wu;       /* optional (prec == F32, vae_wino_ok(a)): the Winograd-transformed weights vae_wino_weights(a, Wu) built from
                           * W; the 3x3 stride-1 layer then runs as F(2x2,3x3): 16 instead of 36 multiplications per 2x2 outputs */
-  int32_t out_bf16;      /* != 0 (vae_conv_out_bf16_ok(a)): C is a bf16 tensor (2 B per element, same [m][ldc] layout): the dgrad
-                          * outputs of bf16 mode, read back by vae_gn_bwd_* (g_bf16); no bias / res / track / gstat with it   */
+  /* storage of the operands in bf16 mode (all zero = fp32 everywhere); vae_conv_io16_ok(a) tells whether the kernel that
+   * serves `a` honours the combination that is set:                                                                      */
+  int32_t out_bf16;      /* C is a bf16 tensor (2 B per element, same [m][ldc] layout); bias / res / gstat / c_step apply as ever
+                          * (the statistics epilogue then describes the ROUNDED values, i.e. the tensor as stored); no track   */
+  int32_t a_bf16;        /* A itself is a bf16 tensor (same layout) and xf still applies: the flat and the <= 4-channel kernels.
+                          * (A16 is the other case: an already transformed image next to / instead of A, xf == NONE.)          */
+  int32_t res_bf16;      /* res is a bf16 tensor                                                                               */
 } vae_igemm_args;
 int vae_igemm_rows(const vae_igemm_args* a, void* stream);
 /* number of chunks per image the launch for `a` (with a->gstat_groups set) would write into a->gstat, or 0 when the
@@ -124,8 +132,10 @@ int vae_conv_gstat_chunks(const vae_igemm_args* a);
 int vae_wino_ok(const vae_igemm_args* a);
 int64_t vae_wino_weight_floats(const vae_igemm_args* a);
 int vae_wino_weights(const vae_igemm_args* a, float* Wu, void* stream);
-/* 1 when the kernel that would serve `a` can write a bf16 output (a->out_bf16): the bf16 halo-tile kernels, dgrad      */
-int vae_conv_out_bf16_ok(const vae_igemm_args* a);
+/* 1 when the kernel that would serve `a` honours a->out_bf16 / a->a_bf16 / a->res_bf16 exactly as they are set (with all
+ * three zero: always 1).  The bf16 flat kernels take any combination; the halo-tile kernels bf16 outputs with a residual of
+ * the same storage; the <= 4-channel kernels the flag of their wide side; fp32-arithmetic kernels none.                  */
+int vae_conv_io16_ok(const vae_igemm_args* a);
 /* 1 when the kernel that would serve `a` honours tapmask / a_step.. / c_step.. (the halo-tile kernels), else 0     */
 int vae_conv_phase_ok(const vae_igemm_args* a);
 /* W [Co][3][3][Ci] (OHWI) -> Weff [4 phases (a*2+b)][Co][3][3][Ci]: the 3x3 kernel each output parity (a,b) of
@@ -162,6 +172,8 @@ typedef struct vae_wgrad_args {
    * (the others are written as zeros).  vae_upconv_fold_wgrad turns the four phase results into the 3x3 gradient.     */
   int32_t tapmask;
   int32_t y_step, y_oy, y_ox;
+  int32_t x_bf16, y_bf16; /* X / dY themselves are bf16 tensors (xf still applies to X): the bf16 flat kernel and the wide side of
+                           * the <= 4-channel kernels (vae_wgrad_io16_ok); the halo-tile kernel takes images through X16 / dY16 */
 } vae_wgrad_args;
 int vae_wgrad(const vae_wgrad_args* a, void* stream);
 /* Winograd F(3x3,2x2) weight gradient of plain 3x3 stride-1 layers in fp32 (csrc/wgrad3_wino.hip; 2.25x fewer multiplications
@@ -174,6 +186,8 @@ int vae_wgrad_wino_plan(const vae_wgrad_args* a, int32_t* nsplit);
 int vae_wgrad_wino(const vae_wgrad_args* a, void* stream);
 int vae_wgrad_wino_reduce(const float* slab, int32_t nsplit, int32_t Cin, int32_t Cout, float* scratch, float* dW,
                           const float* bias_partial, float* db, void* stream);
+/* 1 when the kernel serving `a` honours a->x_bf16 / a->y_bf16 as they are set */
+int vae_wgrad_io16_ok(const vae_wgrad_args* a);
 /* 1 when the kernel serving `a` honours tapmask / y_step.. (the fp32 halo-tile wgrad kernel)                       */
 int vae_wgrad_phase_ok(const vae_wgrad_args* a);
 /* transpose of vae_upconv_phase_weights: dWeff [4][Co][3][3][Ci] (+ dbeff [4][Co] or NULL) -> dW [Co][3][3][Ci] (+ db) */
@@ -281,6 +295,10 @@ int vae_nhwc_to_nchw(const float* src, int32_t B, int32_t C, int32_t HW, float* 
 /* dst[b][y][x][c] = sum of the 2x2 block of src[b][2y..][2x..][c] (dgrad of nearest-up2x) */
 int vae_sumpool2x2(const float* src, int32_t B, int32_t H, int32_t W, int32_t C, float* dst, void* stream);
 int vae_add(const float* a, const float* b, int64_t n, float* out, void* stream);
+/* the same on bf16 tensors (fp32 sum, one rounding); n % 4 == 0 */
+int vae_add_bf16(const void* a, const void* b, int64_t n, void* out, void* stream);
+/* dst[i] = float(src16[i]): a bf16-stored activation for a consumer that needs fp32 (foreign hooks, fp32-only kernels) */
+int vae_unpack_bf16(const void* src16, int64_t n, float* dst, void* stream);
 /* dst[i] = bf16(src[i]) (round to nearest even): the bf16 weight image the bf16 kernels read through vae_igemm_args.Wh;
  * run on the whole parameter arena once per step (replaces the per-step autocast weight casts of the reference) */
 int vae_pack_bf16(const float* src, int64_t n, void* dst, void* stream);

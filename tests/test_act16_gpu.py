@@ -1,0 +1,268 @@
+"""bf16 STORAGE of activations and gradients in bf16 mode (round 3: what autocast keeps for the reference, src/train.py:147-154):
+every kernel that reads or writes an activation tensor, with that tensor stored as bf16, against the SAME kernel on the fp32
+copy of the same values.  A bf16 operand is converted to fp32 on load and runs through the same arithmetic in the same order,
+and a bf16 result is the fp32 result rounded once -- so the comparisons are bitwise wherever the same kernel serves both calls.
+The arithmetic itself is pinned by tests/test_kernels_gpu.py (fp32 storage, against torch's CPU ops)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def _to_dev_ohwi(w):
+    return w.permute(0, 2, 3, 1).contiguous().cuda().permute(0, 3, 1, 2)
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.fixture
+def act16(cuda):
+    """bf16 arithmetic + bf16 activation storage + a bf16 image of every weight handed over (what the engine sets up)"""
+    from vaehip import ops
+    keep = []
+    ops.PRECISION = ops.PREC_BF16
+    assert ops.ACT_BF16
+
+    def pack(wd):
+        buf = wd.permute(0, 2, 3, 1) if wd.ndim == 4 else wd
+        assert buf.is_contiguous()
+        img = torch.empty(buf.numel(), device="cuda", dtype=torch.bfloat16)
+        ops.pack_bf16(buf, img)
+        keep.append(img)
+        ops.WEIGHTS16 = (buf.data_ptr(), buf.numel() * 4, img.data_ptr())
+        return wd
+    yield pack
+    ops.PRECISION, ops.WEIGHTS16 = ops.PREC_F32, None
+
+
+def _names(prof):
+    return [r[0] for r in prof.records]
+
+
+# kind, B, H, W, Ci, Co, kernel family expected for the forward
+FWD_CASES = [("c3", 2, 8, 32, 128, 128, "conv3_tile_bf16"),      # 128-pixel halo-tile kernel (residual on a 128-channel contraction)
+             ("c3", 3, 64, 64, 256, 512, "conv3_wide_bf16"),     # wide-tile kernel, 4 channel tiles
+             ("c3", 7, 40, 96, 256, 256, "conv3_wide_bf16"),
+             ("c3", 1, 5, 7, 128, 128, "igemm_rows_bf16"),       # ragged: flat kernel
+             ("c1", 2, 16, 16, 256, 128, "igemm_rows_bf16"),
+             ("c3s2", 2, 32, 32, 128, 128, "igemm_rows_bf16")]
+
+
+@pytest.mark.parametrize("kind,B,H,W,Ci,Co,family", FWD_CASES)
+def test_conv_forward_and_dgrad_with_bf16_storage(act16, kind, B, H, W, Ci, Co, family):
+    from vaehip import ops
+    gen = torch.Generator().manual_seed(3 + Ci + Co + H)
+    k = 1 if kind == "c1" else 3
+    x16 = _nhwc(torch.randn(B, Ci, H, W, generator=gen) * 1.2 + 0.1).bfloat16()
+    w = torch.randn(Co, Ci, k, k, generator=gen) / math.sqrt(Ci * k * k)
+    wd = act16(_to_dev_ohwi(w))
+    bias = torch.randn(Co, generator=gen).cuda()
+    Ho, Wo = ops.out_hw(kind, H, W)
+    res16 = torch.randn(B, Ho, Wo, Co, generator=gen).cuda().bfloat16()
+    prof = ops.PROFILER = ops.LaunchProfiler()
+    try:
+        y16 = ops.conv_fwd(x16, wd, bias, kind, res=res16, gstat_groups=32)
+        # the same kernel on the same operand values with fp32 output / residual
+        y32 = ops.conv_fwd(x16.float(), wd, bias, kind, res=res16.float(), a16=x16 if family != "igemm_rows_bf16" else None,
+                           gstat_groups=32, out_dtype=torch.float32)
+    finally:
+        ops.PROFILER = None
+    assert y16.dtype == torch.bfloat16 and y32.dtype == torch.float32
+    assert all(n.startswith(family) for n in _names(prof)), _names(prof)
+    assert torch.equal(y16, y32.bfloat16()), _rel(y16.float(), y32)
+    # against torch on the rounded operands (the arithmetic), at the accuracy of one bf16 rounding of the result
+    xr = x16.float().cpu().permute(0, 3, 1, 2)
+    wr = w.bfloat16().float()
+    if kind == "c3s2":
+        ref = F.conv2d(F.pad(xr, (0, 1, 0, 1)), wr, bias.cpu(), 2, 0)
+    else:
+        ref = F.conv2d(xr, wr, bias.cpu(), 1, k // 2)
+    ref = ref + res16.float().cpu().permute(0, 3, 1, 2)
+    assert _rel(y16.float().permute(0, 3, 1, 2), ref) < 6e-3  # 2^-8 relative per element
+    # GroupNorm statistics from the epilogue describe the tensor AS STORED
+    if hasattr(y16, "_gstat"):
+        g1, b1 = torch.ones(Co, device="cuda"), torch.zeros(Co, device="cuda")
+        st_f, st_p = ops.gn_stats(y16, g1, b1), ops.gn_stats(y16.clone(), g1, b1)
+        assert _rel(st_f.mean, st_p.mean) < 1e-5 and _rel(st_f.rstd, st_p.rstd) < 1e-5
+    else:
+        assert family == "igemm_rows_bf16"
+    # dgrad: a bf16 gradient in, a bf16 input gradient out = the fp32 result rounded once
+    dy16 = torch.randn(B, Ho, Wo, Co, generator=gen).cuda().bfloat16()
+    d16 = ops.conv_dgrad(dy16, wd, kind, (H, W))
+    d32 = ops.conv_dgrad(dy16, wd, kind, (H, W), out_dtype=torch.float32)
+    assert d16.dtype == torch.bfloat16 and d32.dtype == torch.float32 and torch.equal(d16, d32.bfloat16())
+    xg = xr.clone().requires_grad_(True)
+    yy = F.conv2d(F.pad(xg, (0, 1, 0, 1)), wr, None, 2, 0) if kind == "c3s2" else F.conv2d(xg, wr, None, 1, k // 2)
+    (gx,) = torch.autograd.grad(yy, xg, dy16.float().cpu().permute(0, 3, 1, 2))
+    assert _rel(d32.permute(0, 3, 1, 2), gx) < 3e-5
+    # wgrad: both operands bf16 tensors == both operands fp32 copies (rounded identically inside the kernel)
+    gw = [torch.empty_like(wd.permute(0, 2, 3, 1).contiguous()).permute(0, 3, 1, 2) for _ in range(2)]
+    gb = [torch.empty(Co, device="cuda") for _ in range(2)]
+    ops.conv_wgrad(dy16, x16, kind, gw[0], gb[0])
+    ops.conv_wgrad(dy16.float(), x16.float(), kind, gw[1], gb[1])
+    assert _rel(gw[0], gw[1]) < 2e-5 and _rel(gb[0], gb[1]) < 1e-6  # (the halo-tile / flat choice may differ between the two calls)
+    wg = wr.clone().requires_grad_(True)
+    yy = F.conv2d(F.pad(xr, (0, 1, 0, 1)), wg, None, 2, 0) if kind == "c3s2" else F.conv2d(xr, wg, None, 1, k // 2)
+    yy.backward(dy16.float().cpu().permute(0, 3, 1, 2))
+    assert _rel(gw[0].cpu(), wg.grad) < 3e-5
+
+
+@pytest.mark.parametrize("C,H,W,silu", [(128, 16, 16, True), (512, 6, 10, False), (256, 8, 32, True)])
+def test_groupnorm_kernels_on_bf16_storage(cuda, C, H, W, silu):
+    """statistics, apply, image, tracker and backward read a bf16 x exactly as they read its fp32 copy"""
+    from vaehip import ops
+    gen = torch.Generator().manual_seed(7 + C)
+    B = 2
+    x16 = _nhwc(torch.randn(B, C, H, W, generator=gen) * 1.3 + 0.4).bfloat16()
+    x32 = x16.float()
+    gamma, beta = (1 + 0.3 * torch.randn(C, generator=gen)).cuda(), (0.2 * torch.randn(C, generator=gen)).cuda()
+    s16, s32 = ops.gn_stats(x16, gamma, beta), ops.gn_stats(x32, gamma, beta)
+    assert torch.equal(s16.mean, s32.mean) and torch.equal(s16.rstd, s32.rstd) and torch.equal(s16.scale, s32.scale)
+    xf = ops.XF_AFFINE_SILU if silu else ops.XF_AFFINE
+    assert torch.equal(ops.gn_apply(x16, s16, xf), ops.gn_apply(x32, s32, xf))
+    assert torch.equal(ops.gn_apply_bf16(x16, s16, xf), ops.gn_apply_bf16(x32, s32, xf))
+    assert torch.equal(ops.gn_track(x16, s16), ops.gn_track(x32, s32))
+    g16 = torch.randn(B, H, W, C, generator=gen).cuda().bfloat16()
+    add16 = torch.randn(B, H, W, C, generator=gen).cuda().bfloat16()
+    dg, db = [torch.empty(C, device="cuda") for _ in range(2)], [torch.empty(C, device="cuda") for _ in range(2)]
+    d16 = ops.gn_bwd(x16, g16, s16, gamma, beta, silu, add16, dg[0], db[0], want32=False, want16=True)
+    d32 = ops.gn_bwd(x32, g16, s32, gamma, beta, silu, add16.float(), dg[1], db[1], want32=True, want16=False)
+    assert d16.dtype == torch.bfloat16 and torch.equal(d16, d32.bfloat16()) and torch.equal(dg[0], dg[1]) and torch.equal(db[0], db[1])
+    # an fp32 gradient with bf16 x / add (the attention block's GroupNorm backward)
+    d16b = ops.gn_bwd(x16, g16.float(), s16, gamma, beta, silu, add16, dg[0], db[0], want32=False, want16=True)
+    assert torch.equal(d16b, d16)
+    # add / unpack helpers
+    assert torch.equal(ops.add(x16, add16), (x32 + add16.float()).bfloat16()) and torch.equal(ops.to_f32(x16), x32)
+
+
+def test_fused_transform_on_bf16_storage(act16):
+    """flat kernels: GroupNorm(+SiLU) applied on load to an operand stored as bf16 (a_bf16 / x_bf16), 1x1 and stride-2 layers"""
+    from vaehip import ops
+    gen = torch.Generator().manual_seed(17)
+    B, C, H, W, Co = 2, 256, 16, 16, 128
+    x16 = _nhwc(torch.randn(B, C, H, W, generator=gen) + 0.3).bfloat16()
+    gamma, beta = (1 + 0.3 * torch.randn(C, generator=gen)).cuda(), (0.2 * torch.randn(C, generator=gen)).cuda()
+    st = ops.gn_stats(x16, gamma, beta)
+    for kind, k in (("c1", 1), ("c3s2", 3)):
+        wd = act16(_to_dev_ohwi(torch.randn(Co, C, k, k, generator=gen) / math.sqrt(C * k * k)))
+        y16 = ops.conv_fwd(x16, wd, None, kind, xf=ops.XF_AFFINE_SILU, stats=st)
+        y32 = ops.conv_fwd(x16.float(), wd, None, kind, xf=ops.XF_AFFINE_SILU, stats=st, out_dtype=torch.float32)
+        assert y16.dtype == torch.bfloat16 and torch.equal(y16, y32.bfloat16())
+        dy16 = torch.randn(y16.shape, generator=gen).cuda().bfloat16()
+        gw = [torch.empty_like(wd.permute(0, 2, 3, 1).contiguous()).permute(0, 3, 1, 2) for _ in range(2)]
+        ops.conv_wgrad(dy16, x16, kind, gw[0], None, xf=ops.XF_AFFINE_SILU, stats=st)
+        ops.conv_wgrad(dy16.float(), x16.float(), kind, gw[1], None, xf=ops.XF_AFFINE_SILU, stats=st)
+        assert torch.equal(gw[0], gw[1])
+
+
+def test_narrow_side_kernels_with_bf16_wide_side(act16):
+    """conv_in (3 -> 128, tracked), conv_out (128 -> 3 behind GroupNorm+SiLU), the latent convs: the wide side bf16, the narrow
+    side, the weights and the arithmetic fp32 (csrc/skinny.hip)"""
+    from vaehip import ops
+    gen = torch.Generator().manual_seed(23)
+    B, H, W = 2, 16, 32
+    # conv_in: fp32 image (padded to 4 channels) -> 128 channels stored as bf16, tracker partials from the stored values
+    x4 = _nhwc(torch.cat([torch.randn(B, 3, H, W, generator=gen), torch.zeros(B, 1, H, W)], 1))
+    w_in = act16(_to_dev_ohwi(torch.randn(128, 3, 3, 3, generator=gen) / 5))
+    b_in = torch.randn(128, generator=gen).cuda()
+    tb16, tb32 = ops.conv_track_buffer(B * H * W, 128, "cuda"), ops.conv_track_buffer(B * H * W, 128, "cuda")
+    prof = ops.PROFILER = ops.LaunchProfiler()
+    try:
+        y16 = ops.conv_fwd(x4, w_in, b_in, "c3", track=tb16)
+        y32 = ops.conv_fwd(x4, w_in, b_in, "c3", track=tb32, out_dtype=torch.float32)
+    finally:
+        ops.PROFILER = None
+    assert _names(prof) == ["conv_smallk_kernel"] * 2 and y16.dtype == torch.bfloat16 and torch.equal(y16, y32.bfloat16())
+    t16 = ops.track_final(tb16, B * H * W)
+    assert _rel(t16, y16.float().abs().mean(dim=(0, 1, 2))) < 1e-5 and _rel(t16, ops.track_final(tb32, B * H * W)) < 5e-3
+    # its weight gradient: dY wide (bf16), X narrow (fp32)
+    dy16 = torch.randn(B, H, W, 128, generator=gen).cuda().bfloat16()
+    gw = [torch.empty(128, 3, 3, 3, device="cuda").permute(0, 3, 1, 2) for _ in range(2)]
+    gb = [torch.empty(128, device="cuda") for _ in range(2)]
+    ops.conv_wgrad(dy16, x4, "c3", gw[0], gb[0])
+    ops.conv_wgrad(dy16.float(), x4, "c3", gw[1], gb[1])
+    assert torch.equal(gw[0], gw[1]) and torch.equal(gb[0], gb[1])
+    # conv_out: GroupNorm+SiLU fused on a bf16 input, 3 fp32 outputs; dgrad back to a bf16 128-channel gradient; wgrad
+    h16 = _nhwc(torch.randn(B, 128, H, W, generator=gen) + 0.2).bfloat16()
+    gamma, beta = (1 + 0.3 * torch.randn(128, generator=gen)).cuda(), (0.2 * torch.randn(128, generator=gen)).cuda()
+    st = ops.gn_stats(h16, gamma, beta)
+    w_out = act16(_to_dev_ohwi(torch.randn(3, 128, 3, 3, generator=gen) / 30))
+    prof = ops.PROFILER = ops.LaunchProfiler()
+    try:
+        r16 = ops.conv_fwd(h16, w_out, None, "c3", xf=ops.XF_AFFINE_SILU, stats=st)
+        r32 = ops.conv_fwd(h16.float(), w_out, None, "c3", xf=ops.XF_AFFINE_SILU, stats=st)
+        dr = torch.randn(B, H, W, 3, generator=gen).cuda()
+        g16 = ops.conv_dgrad(dr, w_out, "c3", (H, W))
+        g32 = ops.conv_dgrad(dr, w_out, "c3", (H, W), out_dtype=torch.float32)
+    finally:
+        ops.PROFILER = None
+    assert _names(prof) == ["conv_smalln_kernel<2>"] * 2 + ["conv_smallk_kernel"] * 2, _names(prof)
+    assert r16.dtype == torch.float32 and torch.equal(r16, r32)
+    assert g16.dtype == torch.bfloat16 and torch.equal(g16, g32.bfloat16())
+    gw = [torch.empty(3, 3, 3, 128, device="cuda").permute(0, 3, 1, 2) for _ in range(2)]
+    ops.conv_wgrad(dr, h16, "c3", gw[0], None, xf=ops.XF_AFFINE_SILU, stats=st)
+    ops.conv_wgrad(dr, h16.float(), "c3", gw[1], None, xf=ops.XF_AFFINE_SILU, stats=st)
+    assert torch.equal(gw[0], gw[1])
+    # decoder.conv_in (4 -> 512): fp32 latents in, bf16 out; its dgrad: a bf16 512-channel gradient -> 4 fp32 channels
+    z = _nhwc(torch.randn(B, 4, 8, 8, generator=gen))
+    w_z = act16(_to_dev_ohwi(torch.randn(512, 4, 3, 3, generator=gen) / 6))
+    h = ops.conv_fwd(z, w_z, None, "c3")
+    assert h.dtype == torch.bfloat16 and torch.equal(h, ops.conv_fwd(z, w_z, None, "c3", out_dtype=torch.float32).bfloat16())
+    dh16 = torch.randn(B, 8, 8, 512, generator=gen).cuda().bfloat16()
+    dz = ops.conv_dgrad(dh16, w_z, "c3", (8, 8))
+    assert dz.dtype == torch.float32 and torch.equal(dz, ops.conv_dgrad(dh16.float(), w_z, "c3", (8, 8)))
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co", [(13, 32, 64, 128, 256), (2, 4, 32, 128, 128)])
+def test_upsampler_phase_convolutions_with_bf16_storage(act16, B, H, W, Ci, Co):
+    """conv3x3(nearest_upsample_2x(x)) on a bf16 x: bf16 output through the strided view, bf16 gradients back"""
+    from vaehip import ops
+    gen = torch.Generator().manual_seed(29 + B)
+    x16 = _nhwc(torch.randn(B, Ci, H, W, generator=gen)).bfloat16()
+    w = torch.randn(Co, Ci, 3, 3, generator=gen) / math.sqrt(9 * Ci)
+    wd = act16(_to_dev_ohwi(w))
+    bias = torch.randn(Co, generator=gen).cuda()
+    y16 = ops.conv_fwd(x16, wd, bias, "c3up")
+    y32 = ops.conv_fwd(x16, wd, bias, "c3up", out_dtype=torch.float32)
+    assert y16.dtype == torch.bfloat16 and y16.shape == (B, 2 * H, 2 * W, Co) and torch.equal(y16, y32.bfloat16())
+    ref = F.conv2d(F.interpolate(x16.float().cpu().permute(0, 3, 1, 2), scale_factor=2.0, mode="nearest"), w.bfloat16().float(), bias.cpu(), 1, 1)
+    assert _rel(y32.permute(0, 3, 1, 2), ref) < 2e-2  # the phase kernels round SUMS of taps to bf16 (tests/test_kernels_gpu.py holds them to 2e-5 against that)
+    dy16 = torch.randn(y16.shape, generator=gen).cuda().bfloat16()
+    dx16 = ops.conv_dgrad(dy16, wd, "c3up", (H, W))
+    dx32 = ops.conv_dgrad(dy16.float(), wd, "c3up", (H, W), out_dtype=torch.float32)
+    assert dx16.dtype == torch.bfloat16 and _rel(dx16.float(), dx32) < 6e-3
+    gw = [torch.empty_like(wd.permute(0, 2, 3, 1).contiguous()).permute(0, 3, 1, 2) for _ in range(2)]
+    gb = [torch.empty(Co, device="cuda") for _ in range(2)]
+    ops.conv_wgrad(dy16, x16, "c3up", gw[0], gb[0])
+    ops.conv_wgrad(dy16.float(), x16.float(), "c3up", gw[1], gb[1])
+    assert _rel(gw[0], gw[1]) < 2e-5 and _rel(gb[0], gb[1]) < 1e-6
+
+
+def test_storage_flags_are_refused_where_no_kernel_honours_them(cuda):
+    """fp32 arithmetic has fp32 storage: the library says so (vae_conv_io16_ok) and vae_igemm_rows refuses the launch"""
+    import ctypes as C
+    from vaehip import ops
+    from vaehip.lib import VaeHipError, lib
+    x = torch.randn(1, 8, 32, 128, device="cuda")
+    wd = _to_dev_ohwi(torch.randn(128, 128, 3, 3) / 30)
+    y = ops.conv_fwd(x, wd, None, "c3")
+    assert y.dtype == torch.float32 and not ops.act16()
+    a = ops.IgemmArgs()
+    a.A, a.W, a.C = ops._p(x), ops._p(ops.ohwi(wd)), ops._p(y)
+    a.g = ops._fwd_geom("c3", 1, 8, 32, 128)
+    a.M, a.N, a.K, a.ldc, a.sn, a.sk, a.st, a.batch, a.alpha = 256, 128, 128, 128, 9 * 128, 1, 128, 1, 1.0
+    assert lib.query("vae_conv_io16_ok", C.byref(a)) == 1
+    a.out_bf16 = 1
+    assert lib.query("vae_conv_io16_ok", C.byref(a)) == 0
+    with pytest.raises(VaeHipError):
+        lib.call("vae_igemm_rows", C.byref(a), ops._stream())

@@ -15,6 +15,37 @@ __device__ __forceinline__ uint2 pack4(f32x4 v) {
   for (int e = 0; e < 4; ++e) h[e] = (__bf16)v[e];
   return __builtin_bit_cast(uint2, h);
 }
+// 4 bf16 (as loaded: 8 bytes) -> 4 fp32
+__device__ __forceinline__ f32x4 unpack4(uint2 r) {
+  f32x4 v;
+  v[0] = __builtin_bit_cast(float, r.x << 16);
+  v[1] = __builtin_bit_cast(float, r.x & 0xffff0000u);
+  v[2] = __builtin_bit_cast(float, r.y << 16);
+  v[3] = __builtin_bit_cast(float, r.y & 0xffff0000u);
+  return v;
+}
+// 4 consecutive elements of an operand stored as fp32 (16-byte load) or bf16 (8-byte load) through a buffer descriptor whose
+// range is in BYTES of that storage; `eoff` = ELEMENT offset of the quad, or a negative value for "out of range" (reads zeros)
+__device__ __forceinline__ f32x4 buf_load4_elems(__amdgpu_buffer_rsrc_t rs, bool bf, int eoff) {
+  if (bf) {
+    const unsigned off = eoff >= 0 ? (unsigned)eoff * 2u : BUF_OOB;
+    return unpack4(__builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0)));
+  }
+  return VAE_BUF_LOAD4(rs, eoff >= 0 ? (unsigned)eoff * 4u : BUF_OOB);
+}
+// one element through a descriptor (fp32: 4-byte, bf16: 2-byte access); eoff < 0 = out of range
+__device__ __forceinline__ float buf_load1_elem(__amdgpu_buffer_rsrc_t rs, bool bf, int eoff) {
+  if (bf) return __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, eoff >= 0 ? (unsigned)eoff * 2u : BUF_OOB, 0, 0) << 16);
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, eoff >= 0 ? (unsigned)eoff * 4u : BUF_OOB, 0, 0));
+}
+__device__ __forceinline__ void buf_store1_elem(__amdgpu_buffer_rsrc_t rs, bool bf, int eoff, float v) {
+  if (bf) {
+    const __bf16 h = (__bf16)v;
+    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h), rs, eoff >= 0 ? (unsigned)eoff * 2u : BUF_OOB, 0, 0);
+  } else {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, eoff >= 0 ? (unsigned)eoff * 4u : BUF_OOB, 0, 0);
+  }
+}
 // MFMA operand from a k-contiguous image: 8 consecutive k at p (one ds_read_b128)
 __device__ __forceinline__ bf16x8 frag_direct(const u16* p) {
   return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(p));

@@ -1,7 +1,8 @@
 // bf16-compute variant of conv3_tile.hip (3x3 stride-1 convolution forward / forward over a virtual
 // nearest-2x upsample / dgrad) for `training.mixed_precision: bf16`:
-//   * activations and outputs stay fp32 in HBM (fp32 statistics); weights are read from `Wh`, a bf16 image of the
-//     fp32 master copy with the same layout (vae_pack_bf16, once per step; without it the flat kernel serves the layer);
+//   * the activation operand is fp32 (transformed and rounded while staged) or a bf16 image (A16); the output fp32 or bf16
+//     (out_bf16, with a bf16 residual); weights are read from `Wh`, a bf16 image of the fp32 master copy with the same
+//     layout (vae_pack_bf16, once per step; without it the flat kernel serves the layer);
 //   * operands are rounded to bf16 while they are staged into LDS (after the fp32 GroupNorm+SiLU transform);
 //   * products run on v_mfma_f32_32x32x16_bf16 (16x the fp32-input MFMA rate), accumulation is fp32.
 // Tiling: 4x32-pixel output tile x 128 channels per workgroup; the halo (6x34 pixels x 32 channels) is shared by the
@@ -326,22 +327,40 @@ __global__ __launch_bounds__(NT, 2) void conv3_tile_bf16_kernel(vae_igemm_args p
       for (int ni = 0; ni < 2; ++ni) {
         const int col = cur.n0 + wn * 64 + ni * 32 + lr;
         const bool colok = col < p.N && oy < g.Ho;
-        if (p.out_bf16) {  // uniform: bf16 output (dgrad of bf16 mode; no bias / residual / statistics).  Adjacent lanes hold
-          // adjacent channels of the same pixels: they swap every other register, so each lane stores two channels of one pixel (4 B)
-          const auto rsC16 = VAE_BUF_RSRC(reinterpret_cast<u16*>(p.C) + (int64_t)cur.b * (g.Ho * cs) * (g.Wo * cs) * p.ldc, obytes / 2);
+        if (p.out_bf16) {  // uniform: bf16 output.  Adjacent lanes hold adjacent channels of the same pixels: they swap every other
+          // register, so each lane ends up with two channels of 8 pixels (4-byte stores, 4-byte loads of the bf16 residual); the
+          // statistics describe the ROUNDED values (see conv3_wide_bf16.hip); no tracker with it
+          const size_t ob16 = (size_t)(g.Ho * cs) * (g.Wo * cs) * p.ldc * 2u;
+          const auto rsC16 = VAE_BUF_RSRC(reinterpret_cast<u16*>(p.C) + (int64_t)cur.b * (g.Ho * cs) * (g.Wo * cs) * p.ldc, ob16);
+          const auto rsR16 = VAE_BUF_RSRC(reinterpret_cast<const u16*>(p.res ? p.res : p.C) + (int64_t)cur.b * (g.Ho * cs) * (g.Wo * cs) * p.ldc, ob16);
           const bool odd = lr & 1;
+          const float b0 = (p.bias && colok) ? p.bias[col & ~1] : 0.f, b1 = (p.bias && colok) ? p.bias[col | 1] : 0.f;
+          unsigned o16[8], rr[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int e = 2 * j + (odd ? 1 : 0);
+            const int ox = cur.x0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            o16[j] = (colok && ox < g.Wo) ? (unsigned)((((oy * cs + (PHASE ? p.c_oy : 0)) * (g.Wo * cs) + ox * cs + (PHASE ? p.c_ox : 0)) * p.ldc + (col & ~1)) * 2) : BUF_OOB;
+            rr[j] = 0u;
+          }
+          if (p.res) {  // uniform
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rr[j] = __builtin_amdgcn_raw_buffer_load_b32(rsR16, o16[j], 0, 0);
+          }
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const float a0 = p.alpha * acc[mi][ni][2 * j], a1 = p.alpha * acc[mi][ni][2 * j + 1];
             const float recv = __shfl_xor(odd ? a0 : a1, 1, 64);
             typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
             bf16x2_t h;
-            h[0] = (__bf16)(odd ? recv : a0);
-            h[1] = (__bf16)(odd ? a1 : recv);
-            const int rr = 2 * j + (odd ? 1 : 0);
-            const int ox = cur.x0 + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
-            const unsigned o16 = (colok && ox < g.Wo) ? (unsigned)((((oy * cs + (PHASE ? p.c_oy : 0)) * (g.Wo * cs) + ox * cs + (PHASE ? p.c_ox : 0)) * p.ldc + (col & ~1)) * 2) : BUF_OOB;
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, h), rsC16, o16, 0, 0);
+            h[0] = (__bf16)((odd ? recv : a0) + b0 + __builtin_bit_cast(float, rr[j] << 16));
+            h[1] = (__bf16)((odd ? a1 : recv) + b1 + __builtin_bit_cast(float, rr[j] & 0xffff0000u));
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, h), rsC16, o16[j], 0, 0);
+            const float q0 = (float)h[0], q1 = (float)h[1];
+            if (j == 0) gpv[mi][ni] = q0;
+            const float d0 = q0 - gpv[mi][ni], d1 = q1 - gpv[mi][ni];
+            gs1[mi][ni] += d0 + d1;
+            gs2[mi][ni] += d0 * d0 + d1 * d1;
             acc[mi][ni][2 * j] = 0.f;
             acc[mi][ni][2 * j + 1] = 0.f;
           }

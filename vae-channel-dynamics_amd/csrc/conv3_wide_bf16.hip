@@ -1,7 +1,7 @@
 // 3x3 stride-1 convolution, forward and dgrad, for bf16 mode when BOTH operands already are bf16 images in HBM
 // (forward: the transformed activation image A16 of vae_gn_apply_bf16; dgrad: the gradient image a bf16 GroupNorm
-// backward / dgrad left, also passed as A16) and the weights come from their bf16 image Wh.  Output fp32 (bias,
-// residual, tracker and GroupNorm-statistics epilogues) or bf16 (out_bf16, dgrad).
+// backward / dgrad left, also passed as A16) and the weights come from their bf16 image Wh.  Output fp32 or bf16 (out_bf16),
+// both with the bias, residual (stored like the output) and GroupNorm-statistics epilogues.
 //
 // Why another kernel next to conv3_tile_bf16.hip: that one feeds 64x64 wave tiles from a 128-pixel halo and re-stages
 // the whole 128-channel weight tile per 128 pixels -- one KB of LDS operand reads per MFMA plus 24 KB of weight writes per
@@ -301,30 +301,57 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
     float* scratch = reinterpret_cast<float*>(sHalo + (hpar ^ 1) * SH);  // the halo buffer of the chunk just finished
     const size_t obytes = (size_t)(g.Ho * cs) * (g.Wo * cs) * p.ldc * 4u;
     const auto rsC = VAE_BUF_RSRC(p.C + (int64_t)cur.b * (g.Ho * cs) * (g.Wo * cs) * p.ldc, obytes);
-    const auto rsC16 = VAE_BUF_RSRC(reinterpret_cast<u16*>(p.C) + (int64_t)cur.b * g.Ho * g.Wo * p.ldc, obytes / 2);
     const auto rsR = VAE_BUF_RSRC((p.res ? p.res : p.C) + (int64_t)cur.b * (g.Ho * cs) * (g.Wo * cs) * p.ldc, obytes);
     float gs1[4][2], gs2[4][2], gpv[4][2];  // statistics as shifted sums around the lane's first value
-    if (p.out_bf16) {  // uniform: adjacent lanes (adjacent channels) swap every other register: 4-byte stores
+    if (p.out_bf16) {
+      // bf16 output (uniform): adjacent lanes hold adjacent channels of the same 16 pixels; they swap every other register, so a
+      // lane ends up with BOTH channels of its pair at 8 pixels: 4-byte stores, 4-byte loads of the bf16 residual (res_bf16), bias
+      // of both channels.  The statistics epilogue below sums the ROUNDED values (the tensor as stored); a lane's 16 values still
+      // belong to one group, so the group merge is the same as for fp32 outputs.
+      const bool odd = lr & 1;
+      const size_t ob16 = (size_t)(g.Ho * cs) * (g.Wo * cs) * p.ldc * 2u;
+      const auto rsC16 = VAE_BUF_RSRC(reinterpret_cast<u16*>(p.C) + (int64_t)cur.b * (g.Ho * cs) * (g.Wo * cs) * p.ldc, ob16);
+      const auto rsR16 = VAE_BUF_RSRC(reinterpret_cast<const u16*>(p.res ? p.res : p.C) + (int64_t)cur.b * (g.Ho * cs) * (g.Wo * cs) * p.ldc, ob16);
+      auto off2 = [&](int r, int ni, int e) -> unsigned {  // byte offset of the lane pair's two channels at pixel e
+        const int oy = cur.y0 + 4 * wm + r, col = cur.n0 + wn * 64 + ni * 32 + lr;
+        const int ox = cur.x0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const bool ok = col < p.N && oy < g.Ho && ox < g.Wo;
+        if (KS == 2) return ok ? (unsigned)((((oy * cs + p.c_oy) * (g.Wo * cs) + ox * cs + p.c_ox) * p.ldc + (col & ~1)) * 2) : BUF_OOB;
+        return ok ? (unsigned)(((oy * g.Wo + ox) * p.ldc + (col & ~1)) * 2) : BUF_OOB;
+      };
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int oy = cur.y0 + 4 * wm + r;
+      for (int hf = 0; hf < 2; ++hf) {
+        unsigned rr[4][8];
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) rr[q][j] = 0u;
+        if (p.res) {  // uniform: the residual of half the wave's tile in flight before any of it is consumed
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rr[q][j] = __builtin_amdgcn_raw_buffer_load_b32(rsR16, off2(2 * hf + (q >> 1), q & 1, 2 * j + (odd ? 1 : 0)), 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int r = 2 * hf + (q >> 1), ni = q & 1;
           const int col = cur.n0 + wn * 64 + ni * 32 + lr;
-          const bool colok = col < p.N && oy < g.Ho;
-          const bool odd = lr & 1;
+          const float b0 = (p.bias && col < p.N) ? p.bias[col & ~1] : 0.f, b1 = (p.bias && col < p.N) ? p.bias[col | 1] : 0.f;
+          gs1[r][ni] = gs2[r][ni] = gpv[r][ni] = 0.f;
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const float a0 = acc[r][ni][2 * j], a1 = acc[r][ni][2 * j + 1];
             const float recv = __shfl_xor(odd ? a0 : a1, 1, 64);
             typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
             bf16x2_t h;
-            h[0] = (__bf16)(odd ? recv : a0);
-            h[1] = (__bf16)(odd ? a1 : recv);
-            const int e = 2 * j + (odd ? 1 : 0);
-            const int ox = cur.x0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-            const unsigned o16 = (colok && ox < g.Wo) ? (unsigned)(((oy * g.Wo + ox) * p.ldc + (col & ~1)) * 2) : BUF_OOB;
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, h), rsC16, o16, 0, 0);
+            h[0] = (__bf16)((odd ? recv : a0) + b0 + __builtin_bit_cast(float, rr[q][j] << 16));
+            h[1] = (__bf16)((odd ? a1 : recv) + b1 + __builtin_bit_cast(float, rr[q][j] & 0xffff0000u));
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, h), rsC16, off2(r, ni, 2 * j + (odd ? 1 : 0)), 0, 0);
+            const float q0 = (float)h[0], q1 = (float)h[1];
+            if (j == 0) gpv[r][ni] = q0;
+            const float d0 = q0 - gpv[r][ni], d1 = q1 - gpv[r][ni];  // (the statistics epilogue only runs on full tiles)
+            gs1[r][ni] += d0 + d1;
+            gs2[r][ni] += d0 * d0 + d1 * d1;
             acc[r][ni][2 * j] = 0.f;
             acc[r][ni][2 * j + 1] = 0.f;
           }
@@ -437,11 +464,11 @@ bool conv3_wide_bf16_eligible(const vae_igemm_args& a) {
   // a residual input on a 128-channel contraction: the tile's main loop (12 stages, ~9 us) is shorter than what one CU needs
   // to pull the 128 KB residual tile and push the 128 KB output (~10 us at a CU's ~26 GB/s), and with one workgroup per CU
   // nothing overlaps the two -- the 128-pixel kernel's second workgroup does (measured 0.505 vs 0.588 ms at 128->128 @256^2)
-  if (a.res != nullptr && a.K <= 128 && !a.out_bf16 && a.tapmask == 0) return false;
+  if (a.res != nullptr && a.K <= 128 && a.tapmask == 0) return false;
   const bool phase = a.tapmask != 0 || a.a_step > 1 || a.c_step > 1;
   if (phase) {
     int kh0, kw0;
-    if (!phase_block(a.tapmask, &kh0, &kw0) || a.out_bf16 || a.gstat) return false;
+    if (!phase_block(a.tapmask, &kh0, &kw0) || a.gstat) return false;
     if ((a.a_step > 1 && a.a_step != 2) || (a.c_step > 1 && a.c_step != 2)) return false;
   }
   const size_t as = a.a_step > 1 ? a.a_step : 1, cs = a.c_step > 1 ? a.c_step : 1;
@@ -449,7 +476,8 @@ bool conv3_wide_bf16_eligible(const vae_igemm_args& a) {
   if (g.Wo % TW != 0 || g.Ho % TH != 0 || a.K % (2 * BK) != 0 || a.N % 8 != 0 || a.N <= 32 || g.Cs % 8 != 0 || a.st % 8 != 0) return false;
   if (g.mode == VAE_MODE_FWD && !(a.sk == 1 && a.sn % 8 == 0)) return false;
   if (g.mode == VAE_MODE_DGRAD && !(a.sn == 1 && a.sk % 8 == 0)) return false;
-  if (a.out_bf16 && (a.bias || a.res || a.track || a.gstat || a.ldc % 2 != 0)) return false;
+  // storage: the operand comes as an image (A16; a_bf16 is the flat kernels' flag); a bf16 output takes a bf16 residual, an fp32 one an fp32 one
+  if (a.a_bf16 || (a.out_bf16 && a.ldc % 2 != 0) || (a.res != nullptr && (a.res_bf16 != 0) != (a.out_bf16 != 0))) return false;
   if (!aligned16(a.A16) || !aligned16(a.Wh)) return false;
   if ((size_t)g.Hs * g.Ws * g.Cs * 4u * as * as >= BUF_MAX || (size_t)g.Ho * g.Wo * a.ldc * 4u * cs * cs >= BUF_MAX) return false;
   if ((size_t)std::max((int64_t)a.K * a.sk, (int64_t)a.N * a.sn) * 2u >= BUF_MAX) return false;

@@ -180,6 +180,36 @@ __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, c
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) o[i] = a[i] + b[i];
 }
 
+// bf16 tensors: o = bf16(float(a) + float(b)), 4 elements per thread per trip
+__device__ __forceinline__ f32x4 unpack4_bf16(uint2 r) {
+  f32x4 v;
+  v[0] = __builtin_bit_cast(float, r.x << 16);
+  v[1] = __builtin_bit_cast(float, r.x & 0xffff0000u);
+  v[2] = __builtin_bit_cast(float, r.y << 16);
+  v[3] = __builtin_bit_cast(float, r.y & 0xffff0000u);
+  return v;
+}
+__global__ __launch_bounds__(256) void add_bf16_kernel(const unsigned short* __restrict__ a, const unsigned short* __restrict__ b, int64_t n4,
+                                                       unsigned short* __restrict__ o) {
+  typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const f32x4 v = unpack4_bf16(*reinterpret_cast<const uint2*>(a + i * 4)) + unpack4_bf16(*reinterpret_cast<const uint2*>(b + i * 4));
+    bf16x4_t h;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) h[e] = (__bf16)v[e];
+    *reinterpret_cast<uint2*>(o + i * 4) = __builtin_bit_cast(uint2, h);
+  }
+}
+__global__ __launch_bounds__(256) void unpack_bf16_kernel(const unsigned short* __restrict__ src, int64_t n, float* __restrict__ dst) {
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256)
+    *reinterpret_cast<f32x4*>(dst + i * 4) = unpack4_bf16(*reinterpret_cast<const uint2*>(src + i * 4));
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t i = (n4 << 2) + threadIdx.x;
+    dst[i] = __builtin_bit_cast(float, (unsigned)src[i] << 16);
+  }
+}
+
 // fp32 -> bf16 image (round to nearest even), 8 elements per thread per trip: 32 B in, 16 B out
 __global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict__ src, int64_t n, unsigned short* __restrict__ dst) {
   typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -481,6 +511,20 @@ extern "C" int vae_add(const float* a, const float* b, int64_t n, float* out, vo
   VAE_CHECK(a && b && out && n > 0, "add: bad args");
   hipLaunchKernelGGL(add_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, n, out);
   VAE_LAUNCH_CHECK("add");
+  return VAE_OK;
+}
+
+extern "C" int vae_add_bf16(const void* a, const void* b, int64_t n, void* out, void* stream) {
+  VAE_CHECK(a && b && out && n > 0 && n % 4 == 0, "add_bf16: bad args (n %% 4 == 0)");
+  hipLaunchKernelGGL(add_bf16_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)a,
+                     (const unsigned short*)b, n / 4, (unsigned short*)out);
+  VAE_LAUNCH_CHECK("add_bf16");
+  return VAE_OK;
+}
+extern "C" int vae_unpack_bf16(const void* src16, int64_t n, float* dst, void* stream) {
+  VAE_CHECK(src16 && dst && n > 0 && (((uintptr_t)src16) & 7u) == 0 && aligned16(dst), "unpack_bf16: bad args");
+  hipLaunchKernelGGL(unpack_bf16_kernel, dim3(ew_blocks((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)src16, n, dst);
+  VAE_LAUNCH_CHECK("unpack_bf16");
   return VAE_OK;
 }
 

@@ -687,11 +687,26 @@ static bool wgrad_use_tile_bf16(const vae_wgrad_args& a) {
   return a.prec == VAE_PREC_BF16 && wgrad3_tile_bf16_eligible(a, wgrad_vec(a)) && !vae_opt().flat_conv;
 }
 
+// operand images (X16 with xf == NONE, dY16) on a layer the bf16 halo-tile kernel does not serve become "X / dY is stored as
+// bf16" for the flat / <= 4-channel kernels (as rows_canon does for A16)
+static vae_wgrad_args wgrad_canon(const vae_wgrad_args& a) {
+  vae_wgrad_args b = a;
+  if ((b.X16 != nullptr || b.dY16 != nullptr) && b.prec == VAE_PREC_BF16 && !wgrad_is_phase(b)) {
+    vae_wgrad_args t = b;
+    if (t.X16 != nullptr && t.xf == VAE_XF_NONE) t.X = reinterpret_cast<const float*>(t.X16);
+    if (t.dY16 != nullptr && t.dY == nullptr) t.dY = reinterpret_cast<const float*>(t.dY16);
+    if (!wgrad_use_tile_bf16(t)) {
+      if (b.X16 != nullptr && b.xf == VAE_XF_NONE) { b.X = reinterpret_cast<const float*>(b.X16); b.X16 = nullptr; b.x_bf16 = 1; }
+      if (b.dY16 != nullptr) { b.dY = reinterpret_cast<const float*>(b.dY16); b.dY16 = nullptr; b.y_bf16 = 1; }
+    }
+  }
+  return b;
+}
 // split-K plan: which nsplit to use for these arguments (a->nsplit is ignored) and whether a->xf can be fused.
 // The caller allocates partial[nsplit][M*taps*N] (+ bias_partial[nsplit][M]) accordingly.
 extern "C" int vae_wgrad_plan(const vae_wgrad_args* ap, int32_t* nsplit, int32_t* xf_fusable) {
   VAE_CHECK(ap && nsplit && xf_fusable, "wgrad_plan: null argument");
-  const vae_wgrad_args& a = *ap;
+  const vae_wgrad_args a = wgrad_canon(*ap);
   // a workgroup keeps the GroupNorm scale/shift rows of every batch item its unit range touches in LDS
   // (SS_HALF entries): the split count is raised until that fits
   auto min_split = [&](int64_t units, int ci_tile) -> int64_t {
@@ -803,14 +818,46 @@ extern "C" int vae_wino_weights(const vae_igemm_args* ap, float* Wu, void* strea
   VAE_LAUNCH_CHECK("wino_weights");
   return VAE_OK;
 }
-extern "C" int vae_conv_out_bf16_ok(const vae_igemm_args* ap) {
-  if (!ap) return 0;
-  const vae_igemm_args& a = *ap;
-  const bool bkm = rows_bkm(a), vec = rows_vec(a, bkm);
-  if (rows_is_phase(a) || a.bias || a.res || a.track || a.gstat || a.N % 8 != 0 || a.ldc % 2 != 0) return 0;
-  if ((a.A16 == nullptr && conv_smallk_eligible(a)) || conv_smalln_eligible(a)) return 0;
-  return rows_use_tile_bf16(a, vec, bkm) ? 1 : 0;
+// An operand image (A16, xf == NONE) on a layer that no halo-tile kernel serves is, for the flat / <= 4-channel kernels, the
+// same thing as "A is stored as bf16": the dispatcher rewrites it that way, so a host may hand over a bf16 tensor as A16
+// without knowing which kernel will run.
+static vae_igemm_args rows_canon(const vae_igemm_args& a) {
+  vae_igemm_args b = a;
+  if (b.A16 != nullptr && b.prec == VAE_PREC_BF16 && b.xf == VAE_XF_NONE && !(b.tapmask != 0 || b.a_step > 1 || b.c_step > 1)) {
+    vae_igemm_args t = b;  // (the vectorisation test reads the pointer the kernel would read)
+    if (t.A == nullptr) t.A = reinterpret_cast<const float*>(t.A16);
+    const bool bkm = rows_bkm(t);
+    if (!rows_use_tile_bf16(t, rows_vec(t, bkm), bkm)) {
+      b.A = reinterpret_cast<const float*>(b.A16);
+      b.A16 = nullptr;
+      b.a_bf16 = 1;
+    }
+  }
+  return b;
 }
+// Storage flags (vaehip.h: out_bf16 / a_bf16 / res_bf16): does the kernel that serves `a` honour them as they are set?  Follows
+// the dispatch order of vae_igemm_rows.
+static bool tile16_flags_ok(const vae_igemm_args& a) {  // the 128-pixel bf16 halo-tile kernel (conv3_tile_bf16.hip)
+  return !a.a_bf16 && (!a.out_bf16 || (a.track == nullptr && a.ldc % 2 == 0 && a.N % 2 == 0)) &&
+         (a.res == nullptr || (a.res_bf16 != 0) == (a.out_bf16 != 0));
+}
+static bool rows_io16_ok(const vae_igemm_args& a0) {
+  const vae_igemm_args a = rows_canon(a0);
+  if (!a.out_bf16 && !a.a_bf16 && !a.res_bf16) return true;
+  if (a.prec != VAE_PREC_BF16 || a.Wu != nullptr) return false;  // fp32-arithmetic kernels: fp32 storage
+  if (a.res_bf16 && a.res == nullptr) return false;
+  const bool bkm = rows_bkm(a), vec = rows_vec(a, bkm);
+  if (rows_is_phase(a)) {
+    if (rows_use_wide_bf16(a, vec, bkm)) return true;  // (its eligibility covers the flags)
+    return a.A16 == nullptr && a.xf == VAE_XF_NONE && rows_use_tile_bf16(a, vec, bkm) && tile16_flags_ok(a);
+  }
+  if (a.A16 == nullptr && conv_smallk_eligible(a)) return !a.a_bf16 && !a.res_bf16;  // wide side = the output
+  if (conv_smalln_eligible(a)) return !a.out_bf16 && !a.res_bf16;                     // wide side = the input
+  if (rows_use_wide_bf16(a, vec, bkm)) return true;
+  if (rows_use_tile_bf16(a, vec, bkm)) return tile16_flags_ok(a);
+  return vec && (a.A16 == nullptr);  // the bf16 flat kernels take any combination; unvectorised shapes run the fp32 kernel
+}
+extern "C" int vae_conv_io16_ok(const vae_igemm_args* ap) { return (ap && rows_io16_ok(*ap)) ? 1 : 0; }
 extern "C" int vae_conv_phase_ok(const vae_igemm_args* ap) {
   if (!ap) return 0;
   const vae_igemm_args& a = *ap;
@@ -821,7 +868,7 @@ extern "C" int vae_conv_phase_ok(const vae_igemm_args* ap) {
 }
 extern "C" int vae_conv_gstat_chunks(const vae_igemm_args* ap) {
   if (!ap) return 0;
-  const vae_igemm_args& a = *ap;
+  const vae_igemm_args a = rows_canon(*ap);
   if (a.Wu != nullptr) return conv3_wino_eligible(a) ? conv3_wino_gstat_chunks(a) : 0;
   const bool bkm = rows_bkm(a), vec = rows_vec(a, bkm);
   if ((a.A16 == nullptr && conv_smallk_eligible(a)) || conv_smalln_eligible(a)) return 0;
@@ -834,7 +881,7 @@ extern "C" int vae_conv_gstat_chunks(const vae_igemm_args* ap) {
 // (profiling labels that match the rocprofv3 kernel names; no launch)
 extern "C" int vae_igemm_kernel_name(const vae_igemm_args* ap, char* buf, int32_t n) {
   VAE_CHECK(ap && buf && n > 0, "igemm_kernel_name: bad args");
-  const vae_igemm_args& a = *ap;
+  const vae_igemm_args a = rows_canon(*ap);
   const bool bkm = rows_bkm(a), vec = rows_vec(a, bkm);
   const char* tf[2] = {"false", "true"};
   if (a.Wu != nullptr && rows_wino(a))
@@ -866,7 +913,7 @@ extern "C" int vae_igemm_kernel_name(const vae_igemm_args* ap, char* buf, int32_
 }
 extern "C" int vae_wgrad_kernel_name(const vae_wgrad_args* ap, char* buf, int32_t n) {
   VAE_CHECK(ap && buf && n > 0, "wgrad_kernel_name: bad args");
-  const vae_wgrad_args& a = *ap;
+  const vae_wgrad_args a = wgrad_canon(*ap);
   const bool vec = wgrad_vec(a);
   const char* tf[2] = {"false", "true"};
   if (wgrad_is_phase(a) && a.prec == VAE_PREC_BF16)
@@ -883,7 +930,8 @@ extern "C" int vae_wgrad_kernel_name(const vae_wgrad_args* ap, char* buf, int32_
 
 extern "C" int vae_igemm_rows(const vae_igemm_args* ap, void* stream) {
   VAE_CHECK(ap != nullptr, "igemm_rows: null args");
-  const vae_igemm_args& a = *ap;
+  const vae_igemm_args a = rows_canon(*ap);
+  ap = &a;
   if (int e = check_geom("igemm_rows", a.g)) return e;
   VAE_CHECK(a.A && a.W && a.C, "igemm_rows: null operand");
   VAE_CHECK(a.M > 0 && a.N > 0 && a.K > 0 && a.batch > 0, "igemm_rows: bad sizes M=%d N=%d K=%d", a.M, a.N, a.K);
@@ -900,7 +948,7 @@ extern "C" int vae_igemm_rows(const vae_igemm_args* ap, void* stream) {
   const bool bkm = rows_bkm(a);
   const bool vec = rows_vec(a, bkm);
   VAE_CHECK(a.gstat == nullptr || vae_conv_gstat_chunks(ap) > 0, "igemm_rows: no statistics epilogue for these arguments (vae_conv_gstat_chunks)");
-  VAE_CHECK(!a.out_bf16 || vae_conv_out_bf16_ok(ap), "igemm_rows: out_bf16 needs a bf16 halo-tile kernel and no bias / res / track / gstat (vae_conv_out_bf16_ok)");
+  VAE_CHECK(rows_io16_ok(a), "igemm_rows: the kernel serving these arguments does not take this combination of out_bf16 / a_bf16 / res_bf16 (vae_conv_io16_ok)");
   hipStream_t st = (hipStream_t)stream;
   if (a.Wu != nullptr) {  // Winograd F(2x2,3x3) with the transformed weights the caller built for THIS geometry
     VAE_CHECK(rows_wino(a) && aligned16(a.Wu), "igemm_rows: Wu needs a layer vae_wino_ok accepts");
@@ -1014,9 +1062,25 @@ extern "C" int vae_wgrad_phase_ok(const vae_wgrad_args* ap) {
   if (ap->prec == VAE_PREC_BF16) return (ap->xf == VAE_XF_NONE && wgrad_use_tile_bf16(*ap)) ? 1 : 0;  // the bf16 halo-tile kernel
   return (ap->X16 == nullptr && wgrad_use_tile(*ap)) ? 1 : 0;
 }
+// storage flags of the weight gradient's operands (vaehip.h: x_bf16 / y_bf16); follows vae_wgrad's dispatch order
+static bool wgrad_io16_ok(const vae_wgrad_args& a0) {
+  const vae_wgrad_args a = wgrad_canon(a0);
+  if (!a.x_bf16 && !a.y_bf16) return true;
+  if (a.prec != VAE_PREC_BF16 || wgrad_is_phase(a)) return false;  // the halo-tile kernels take images through X16 / dY16
+  if (a.X16 == nullptr) {
+    const int kind = wgrad_smallk_kind(a);
+    if (kind) return kind == 1 ? !a.x_bf16 : !a.y_bf16;  // only the wide side may be bf16 (kind 1: dY, kind 2: X)
+  }
+  if (a.X16 != nullptr || a.dY16 != nullptr || wgrad_use_tile_bf16(a) || wgrad_use_tile(a)) return false;
+  return wgrad_vec(a);  // the bf16 flat kernel
+}
+extern "C" int vae_wgrad_io16_ok(const vae_wgrad_args* ap) { return (ap && wgrad_io16_ok(*ap)) ? 1 : 0; }
+
 extern "C" int vae_wgrad(const vae_wgrad_args* ap, void* stream) {
   VAE_CHECK(ap != nullptr, "wgrad: null args");
-  const vae_wgrad_args& a = *ap;
+  const vae_wgrad_args a = wgrad_canon(*ap);
+  ap = &a;
+  VAE_CHECK(wgrad_io16_ok(a), "wgrad: the kernel serving these arguments does not take x_bf16 / y_bf16 as set (vae_wgrad_io16_ok)");
   if (int e = check_geom("wgrad", a.g)) return e;
   VAE_CHECK((a.dY || a.dY16) && a.X, "wgrad: null operand");
   VAE_CHECK(a.dY16 == nullptr || (wgrad_use_tile_bf16(a) && !(a.X16 == nullptr && wgrad_smallk_kind(a)) && aligned16(a.dY16) && a.ldy % 8 == 0 && a.M % 8 == 0),

@@ -1,7 +1,8 @@
 // bf16-compute variants of the flat implicit-GEMM kernels of igemm.hip (VAE_PREC_BF16): every geometry the
 // fp32 flat kernels serve (stride-2 convs, 1x1, parity-class dgrad, tiny spatial sizes, attention linears and
-// batched GEMMs, skinny layers) with fp32 tensors in HBM, operands rounded to bf16 while staged in LDS, products
-// on v_mfma_f32_32x32x16_bf16 and fp32 accumulation.  Only the vectorised (16-B aligned, channel counts % 4 == 0)
+// batched GEMMs, skinny layers): operands rounded to bf16 while staged in LDS, products on v_mfma_f32_32x32x16_bf16, fp32
+// accumulation.  Every activation operand is stored as fp32 or as bf16, per tensor (a_bf16 / out_bf16 / res_bf16, x_bf16 /
+// y_bf16: wave-uniform switches on the load / store instructions; the weights W are always the fp32 master copy).  Only the vectorised (16-B aligned, channel counts % 4 == 0)
 // shapes exist here; the rest stays on the fp32 kernels.
 //   rows : A tile [BM rows][BK k] k-contiguous (one ds_read_b128 per fragment);
 //          weight tile k-contiguous ([BN][BK], ds_read_b128) or n-contiguous ([BK][BN], transposing read)
@@ -37,7 +38,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_rows_bf16_kernel(vae_igemm
   const int m0 = tm * BM, n0 = tn * BN;
   const int z = blockIdx.z;
   const vae_conv_geom g = p.g;
-  const float* __restrict__ A = p.A + (int64_t)z * p.sAb;
+  const bool abf = p.a_bf16 != 0, cbf = p.out_bf16 != 0, rbf = p.res_bf16 != 0;  // storage of A / C / res (uniform)
+  const unsigned esA = abf ? 2u : 4u;
+  const char* __restrict__ A = reinterpret_cast<const char*>(p.A) + (int64_t)z * p.sAb * esA;
   const float* __restrict__ W = p.W + (int64_t)z * p.sWb;
   const int hw = g.Ho * g.Wo;
 
@@ -68,8 +71,8 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_rows_bf16_kernel(vae_igemm
   // operands through buffer descriptors (common.h; same conventions as the fp32 flat kernel)
   const int b_base = s2c ? (m0 - cls * cls_rows) / (hh * wh) : m0 / hw;
   const size_t img = (size_t)g.Hs * g.Ws * g.Cs;
-  const size_t abytes = (size_t)(g.B - b_base) * img * 4u, wbytes = (size_t)(BKM ? (int64_t)p.K * p.sk : (int64_t)p.N * p.sn) * 4u;
-  const auto rsA = VAE_BUF_RSRC(A + (int64_t)b_base * img, abytes < BUF_MAX ? abytes : BUF_MAX);
+  const size_t abytes = (size_t)(g.B - b_base) * img * esA, wbytes = (size_t)(BKM ? (int64_t)p.K * p.sk : (int64_t)p.N * p.sn) * 4u;
+  const auto rsA = VAE_BUF_RSRC(A + (int64_t)b_base * img * esA, abytes < BUF_MAX ? abytes : BUF_MAX);
   const auto rsW = VAE_BUF_RSRC(W, wbytes < BUF_MAX ? wbytes : BUF_MAX);
 
   const int k4 = tid & 15, r0 = tid >> 4;
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_rows_bf16_kernel(vae_igemm
     for (int i = 0; i < AR; ++i) {
       int sy = 0, sx = 0;
       const bool ok = src_pixel(g, ry[i], rx[i], kh, kw, sy, sx) && (rb[i] >= 0);
-      ra[i] = VAE_BUF_LOAD4(rsA, (ok && c < p.K) ? ((unsigned)(((rb[i] - b_base) * g.Hs + sy) * g.Ws + sx) * (unsigned)g.Cs + (unsigned)c) * 4u : BUF_OOB);
+      ra[i] = buf_load4_elems(rsA, abf, (ok && c < p.K) ? (((rb[i] - b_base) * g.Hs + sy) * g.Ws + sx) * g.Cs + c : -1);
       a_b[i] = ok ? rb[i] : -1;
     }
     if (!BKM) {
@@ -213,13 +216,13 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_rows_bf16_kernel(vae_igemm
     __syncthreads();
   }
 
-  // ---------------- epilogue (fp32) ----------------
+  // ---------------- epilogue ----------------
   // outputs and the residual through buffer descriptors (common.h): a row / column outside the matrix is an
   // out-of-range offset (load reads 0, store is dropped): no branch per element, residual loads issued back to back
-  float* __restrict__ C = p.C + (int64_t)z * p.sCb;
-  const size_t obytes = (size_t)p.M * p.ldc * 4u;
-  const auto rsC = VAE_BUF_RSRC(C, obytes);
-  const auto rsR = VAE_BUF_RSRC(p.res ? p.res + (int64_t)z * p.sCb : C, obytes);
+  const unsigned esC = cbf ? 2u : 4u, esR = rbf ? 2u : 4u;
+  char* __restrict__ C = reinterpret_cast<char*>(p.C) + (int64_t)z * p.sCb * esC;
+  const auto rsC = VAE_BUF_RSRC(C, (size_t)p.M * p.ldc * esC);
+  const auto rsR = VAE_BUF_RSRC(p.res ? reinterpret_cast<const char*>(p.res) + (int64_t)z * p.sCb * esR : C, (size_t)p.M * p.ldc * (p.res ? esR : esC));
   float tsum[NI];
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) tsum[ni] = 0.f;
@@ -230,29 +233,29 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_rows_bf16_kernel(vae_igemm
     const float bv = (p.bias && colok) ? p.bias[col] : 0.f;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-      unsigned off[16];
+      int off[16];
       float rv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * TM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        unsigned orow = (unsigned)row;
+        int orow = row;
         if (s2c) {  // class-major row -> pixel-major output row
           int b, y, x;
           row_pixel(row < p.M ? row : m0, b, y, x);
-          orow = (unsigned)((b * g.Ho + y) * g.Wo + x);
+          orow = (b * g.Ho + y) * g.Wo + x;
         }
-        off[r] = (colok && row < p.M) ? (orow * (unsigned)p.ldc + (unsigned)col) * 4u : BUF_OOB;
+        off[r] = (colok && row < p.M) ? orow * p.ldc + col : -1;  // element offset
         rv[r] = 0.f;
       }
       if (p.res) {  // uniform
 #pragma unroll
-        for (int r = 0; r < 16; ++r) rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, off[r], 0, 0));
+        for (int r = 0; r < 16; ++r) rv[r] = buf_load1_elem(rsR, rbf, off[r]);
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float v = p.alpha * acc[mi][ni][r] + bv + rv[r];
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, off[r], 0, 0);
-        tsum[ni] += (off[r] != BUF_OOB) ? fabsf(v) : 0.f;
+        buf_store1_elem(rsC, cbf, off[r], v);
+        tsum[ni] += (off[r] >= 0) ? fabsf(v) : 0.f;
       }
     }
   }
@@ -300,8 +303,10 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_bf16_kernel(vae_wgrad_args
   const int z = blockIdx.z;
   const vae_conv_geom g = p.g;
   const int kh = (g.taps == 9) ? tap / 3 : 0, kw = (g.taps == 9) ? tap - kh * 3 : 0;
-  const float* __restrict__ dY = p.dY + (int64_t)z * p.sYb;
-  const float* __restrict__ X = p.X + (int64_t)z * p.sXb;
+  const bool ybf = p.y_bf16 != 0, xbf = p.x_bf16 != 0;  // storage of dY / X (uniform)
+  const unsigned esY = ybf ? 2u : 4u, esX = xbf ? 2u : 4u;
+  const char* __restrict__ dY = reinterpret_cast<const char*>(p.dY) + (int64_t)z * p.sYb * esY;
+  const char* __restrict__ X = reinterpret_cast<const char*>(p.X) + (int64_t)z * p.sXb * esX;
 
   int chunk = (p.npix + p.nsplit - 1) / p.nsplit;
   chunk = ((chunk + 31) / 32) * 32;  // same rounding as the fp32 kernel (the table-fit check assumes it)
@@ -333,9 +338,9 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_bf16_kernel(vae_wgrad_args
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
   const size_t img = (size_t)g.Hs * g.Ws * g.Cs;
-  const size_t ybytes = (size_t)(steps > 0 ? pend - pbeg : 0) * p.ldy * 4u, xbytes = (size_t)(g.B - b_lo) * img * 4u;
-  const auto rsY = VAE_BUF_RSRC(dY + (int64_t)pbeg * p.ldy, ybytes < BUF_MAX ? ybytes : BUF_MAX);
-  const auto rsX = VAE_BUF_RSRC(X + (int64_t)b_lo * img, xbytes < BUF_MAX ? xbytes : BUF_MAX);
+  const size_t ybytes = (size_t)(steps > 0 ? pend - pbeg : 0) * p.ldy * esY, xbytes = (size_t)(g.B - b_lo) * img * esX;
+  const auto rsY = VAE_BUF_RSRC(dY + (int64_t)pbeg * p.ldy * esY, ybytes < BUF_MAX ? ybytes : BUF_MAX);
+  const auto rsX = VAE_BUF_RSRC(X + (int64_t)b_lo * img * esX, xbytes < BUF_MAX ? xbytes : BUF_MAX);
 
   const int a4 = tid % AQ, akq = tid / AQ;
   const int b4 = tid % BQ, bkq = tid / BQ;
@@ -349,7 +354,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_bf16_kernel(vae_wgrad_args
     for (int i = 0; i < AI; ++i) {
       const int pix = pb + akq + AKR * i;
       const int c = m0 + a4 * 4;
-      ra[i] = VAE_BUF_LOAD4(rsY, (pix < pend && c < p.M) ? ((unsigned)(pix - pbeg) * (unsigned)p.ldy + (unsigned)c) * 4u : BUF_OOB);
+      ra[i] = buf_load4_elems(rsY, ybf, (pix < pend && c < p.M) ? (pix - pbeg) * p.ldy + c : -1);
     }
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
@@ -359,7 +364,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_bf16_kernel(vae_wgrad_args
       const int y = rem / g.Wo, x = rem - y * g.Wo;
       int sy = 0, sx = 0;
       const bool ok = src_pixel(g, y, x, kh, kw, sy, sx) && (pix < pend);
-      rx[i] = VAE_BUF_LOAD4(rsX, (ok && c < p.N) ? ((unsigned)(((b - b_lo) * g.Hs + sy) * g.Ws + sx) * (unsigned)g.Cs + (unsigned)c) * 4u : BUF_OOB);
+      rx[i] = buf_load4_elems(rsX, xbf, (ok && c < p.N) ? (((b - b_lo) * g.Hs + sy) * g.Ws + sx) * g.Cs + c : -1);
       xb[i] = ok ? b : -1;
     }
   };

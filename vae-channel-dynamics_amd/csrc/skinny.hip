@@ -8,7 +8,10 @@
 //   conv_smallk : y[px][n]      = bias[n] + sum_{tap,s} S[src(px,tap)][s] * W[n][tap][s]      (rows form, K <= 4)
 //   wgrad_smallk: out[..]       = sum_px V[px][lane] * S[src(px,tap)][s]                      (N <= 4 or M <= 4)
 //   conv_smalln : y[px][s]      = bias[s] + sum_{tap,c} XF(x)[px+tap][c] * W[s][tap][c]       (<= 4 outputs; end of file)
-#include "common.h"
+// The WIDE side may be stored as bf16 (bf16 mode keeps the 128-channel activations / gradients as bf16): out_bf16 for
+// conv_smallk's output, y_bf16 / x_bf16 for wgrad_smallk's V, a_bf16 for conv_smalln's input; the narrow side, the weights
+// and the arithmetic are fp32.
+#include "bf16_frag.h"
 #include <algorithm>
 
 namespace {
@@ -56,7 +59,8 @@ __global__ __launch_bounds__(NT) void conv_smallk_kernel(vae_igemm_args p) {
     for (int s = 0; s < 4; ++s)
       w[t][s] = (nok && t < g.taps && s < p.K) ? p.W[(int64_t)n * p.sn + (int64_t)t * p.st + (int64_t)s * p.sk] : 0.f;
   const float bv = (p.bias && nok) ? p.bias[n] : 0.f;
-  const size_t obytes = (size_t)p.M * p.ldc * 4u;
+  const bool cbf = p.out_bf16 != 0;
+  const size_t obytes = (size_t)p.M * p.ldc * (cbf ? 2u : 4u);
   const auto rsC = VAE_BUF_RSRC(p.C, obytes);
   __syncthreads();
 
@@ -75,8 +79,9 @@ __global__ __launch_bounds__(NT) void conv_smallk_kernel(vae_igemm_args p) {
     }
     const int m = m0 + row;
     const bool ok = nok && m < p.M;
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc), rsC, ok ? ((unsigned)m * (unsigned)p.ldc + (unsigned)n) * 4u : BUF_OOB, 0, 0);
-    tsum += ok ? fabsf(acc) : 0.f;
+    buf_store1_elem(rsC, cbf, ok ? m * p.ldc + n : -1, acc);
+    const float stored = cbf ? (float)(__bf16)acc : acc;  // the tracker describes the tensor as stored
+    tsum += ok ? fabsf(stored) : 0.f;
   }
   if (p.track) {  // uniform: per-channel sum of |y| over this 128-row tile (same partial layout as the MFMA kernels)
     __syncthreads();
@@ -103,7 +108,8 @@ __global__ __launch_bounds__(NT) void wgrad_smallk_kernel(vae_wgrad_args p, vae_
   const int ldv = SMALL_X ? p.ldy : p.g.Cs, lds_ = SMALL_X ? p.g.Cs : p.ldy;
   const int npixv = gs.B * gs.Ho * gs.Wo;            // pixels of V (= row grid of gs)
   const int hwv = gs.Ho * gs.Wo;
-  const size_t vbytes = (size_t)npixv * ldv * 4u;
+  const bool vbf = (SMALL_X ? p.y_bf16 : p.x_bf16) != 0;  // storage of the wide operand
+  const size_t vbytes = (size_t)npixv * ldv * (vbf ? 2u : 4u);
   const auto rsV = VAE_BUF_RSRC(V, vbytes < BUF_MAX ? vbytes : BUF_MAX);
 
   float acc[TAPS_MAX][4];
@@ -128,7 +134,7 @@ __global__ __launch_bounds__(NT) void wgrad_smallk_kernel(vae_wgrad_args p, vae_
       const int row = half + 2 * i;
       const int m = m0 + row;
       const bool ok = chok && m < npixv;
-      float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsV, ok ? ((unsigned)m * (unsigned)ldv + (unsigned)ch) * 4u : BUF_OOB, 0, 0));
+      float v = buf_load1_elem(rsV, vbf, ok ? m * ldv + ch : -1);
       if (XF != VAE_XF_NONE) {
         const int b = min(m, npixv - 1) / hwv;  // uniform per row
         if (b != xb) {
@@ -261,7 +267,9 @@ __global__ __launch_bounds__(NNT) void conv_smalln_kernel(vae_igemm_args p, int 
   const int b = t / tiles_y;
   const int y0 = ty * NTH, x0 = tx * NTW;
   const int pr = tid >> 5, px = tid & 31;  // this lane's pixel of the tile
-  const auto rsA = VAE_BUF_RSRC(p.A + (int64_t)b * g.Hs * g.Ws * g.Cs, (size_t)g.Hs * g.Ws * g.Cs * 4u);
+  const bool abf = p.a_bf16 != 0;
+  const unsigned esA = abf ? 2u : 4u;
+  const auto rsA = VAE_BUF_RSRC(reinterpret_cast<const char*>(p.A) + (int64_t)b * g.Hs * g.Ws * g.Cs * esA, (size_t)g.Hs * g.Ws * g.Cs * esA);
   const float* __restrict__ W = p.W;
 
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -284,7 +292,7 @@ __global__ __launch_bounds__(NNT) void conv_smalln_kernel(vae_igemm_args p, int 
       const int ir = pp / NHW, jc = pp - ir * NHW;
       const int hy = y0 - 1 + ir, hx = x0 - 1 + jc;
       const bool ok = (q < NHQ) && ((unsigned)hy < (unsigned)g.Hs) && ((unsigned)hx < (unsigned)g.Ws) && (c < p.K);
-      rh[i] = VAE_BUF_LOAD4(rsA, ok ? (unsigned)(((hy * g.Ws + hx) * g.Cs + c) * 4) : BUF_OOB);
+      rh[i] = buf_load4_elems(rsA, abf, ok ? ((hy * g.Ws + hx) * g.Cs + c) : -1);
       hmask |= (ok ? 1 : 0) << i;
     }
   };

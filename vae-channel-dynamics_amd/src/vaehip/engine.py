@@ -133,11 +133,14 @@ class Engine:
                 st = Stats(None, None, one, torch.zeros_like(one))
                 self._ident[key] = st
             return ops.gn_track(t.reshape(B, -1, 1, Cc), st)
-        return t.abs().mean(dim=tuple(range(t.ndim - 1)))
+        return t.float().abs().mean(dim=tuple(range(t.ndim - 1)))
 
     @staticmethod
     def _present(m, t: torch.Tensor) -> torch.Tensor:
-        """NHWC buffer -> the tensor a torch hook on `m` expects (NCHW-logical view; [B,T,C] for Linear)."""
+        """NHWC buffer -> the tensor a torch hook on `m` expects (NCHW-logical view; [B,T,C] for Linear).  A bf16-stored
+        activation is handed over as an fp32 copy: the reference's hooks call .numpy() on it (monitor.py:67), which bf16
+        tensors do not support."""
+        t = ops.to_f32(t)
         if isinstance(m, nn.Linear):
             return t.reshape(t.shape[0], -1, t.shape[-1])
         return t.permute(0, 3, 1, 2)
@@ -183,7 +186,9 @@ class Engine:
             self._post(norm, lambda: x, ops.gn_apply(x, st, XF_AFFINE), tracked_already=True)
         return st
 
-    def _conv(self, m, x: torch.Tensor, xf: int, st: Optional[Stats], res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def _conv(self, m, x: torch.Tensor, xf: int, st: Optional[Stats], res: Optional[torch.Tensor] = None,
+              out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+        """out_dtype: storage of the output when the default (ops.conv_fwd: bf16 for wide layers in bf16 mode) is not wanted"""
         kind = getattr(m, "kind", "c1")
         cache = {}
 
@@ -214,7 +219,7 @@ class Engine:
         # every 3x3 output of this model feeds a GroupNorm(32) next (or is summed first: then the statistics are dropped)
         want_stats = ops.GN_GROUPS if (kind in ("c3", "c3up") and (res is None or fuse_res)) else None
         y = ops.conv_fwd(xin, m.weight, m.bias, kind, xf=xfc, stats=stc, res=res if fuse_res else None, track=tb,
-                         a16=a16 if a16 is not xin else None, gstat_groups=want_stats)
+                         a16=a16 if a16 is not xin else None, gstat_groups=want_stats, out_dtype=out_dtype)
         if sinks:
             v = ops.track_final(tb, y.shape[0] * y.shape[1] * y.shape[2])
             for s in sinks:
@@ -229,9 +234,10 @@ class Engine:
         a16, self._last16 = self._last16, None
         return a16 if recording else None
 
-    def _conv_bwd(self, m, x, dy, xf, st, need_dx=True, x16=None, dx_to_gn=False):
+    def _conv_bwd(self, m, x, dy, xf, st, need_dx=True, x16=None, dx_to_gn=False, dx_dtype=None):
         """dy: fp32 (possibly carrying a bf16 image) or bf16; dx_to_gn: the input gradient goes to a GroupNorm backward and
-        nowhere else, so bf16 mode may store it as bf16"""
+        nowhere else, so bf16 mode may store it as bf16 even with fp32 activation storage; dx_dtype: storage of the input
+        gradient when the default (ops.conv_dgrad) is not wanted"""
         kind = getattr(m, "kind", "c1")
         if (need_dx and dy.dtype == torch.float32 and getattr(dy, "_b16", None) is None
                 and ops.grad_image_ok(kind, x.shape[:3] + (m.weight.shape[1],), m.weight.shape[0], m.weight.shape[1])):
@@ -242,7 +248,7 @@ class Engine:
             x, xf, st, x16 = x16, XF_NONE, None, None
         ops.conv_wgrad(dy, x, kind, self._g(m.weight), self._g(m.bias), xf=xf, stats=st, x16=x16)
         if need_dx:
-            return ops.conv_dgrad(dy, m.weight, kind, (x.shape[1], x.shape[2]), out_bf16=dx_to_gn)
+            return ops.conv_dgrad(dy, m.weight, kind, (x.shape[1], x.shape[2]), out_bf16=dx_to_gn, out_dtype=dx_dtype)
         return None
 
     def _gn_bwd(self, norm, x, g, st, silu, add, conv_only=None, feeds_conv3=False):
@@ -250,7 +256,9 @@ class Engine:
         alone when its kernels take a bf16 gradient image.  feeds_conv3: the result continues the residual stream (fp32) and
         is also the output gradient of a 3x3 convolution upstream: a bf16 image is attached for that consumer."""
         want32, want16 = True, False
-        if conv_only is not None and ops.grad_image_ok(getattr(conv_only, "kind", "c1"), x.shape[:3] + (conv_only.weight.shape[1],),
+        if ops.act16():  # bf16 storage: every activation gradient is a bf16 tensor
+            want32, want16 = False, True
+        elif conv_only is not None and ops.grad_image_ok(getattr(conv_only, "kind", "c1"), x.shape[:3] + (conv_only.weight.shape[1],),
                                                       conv_only.weight.shape[0], conv_only.weight.shape[1]):
             want32, want16 = False, True
         elif feeds_conv3 and ops.grad_image_ok("c3", x.shape, x.shape[3], x.shape[3]):
@@ -324,9 +332,12 @@ class Engine:
         T = H * W
         scale = float(Cc) ** -0.5
         st = self._gn(a.group_norm, x)
-        q = self._conv(a.to_q, x, XF_AFFINE, st)
-        k = self._conv(a.to_k, x, XF_AFFINE, st)
-        v = self._conv(a.to_v, x, XF_AFFINE, st)
+        # the attention block's internals (q, k, v, scores, context and their gradients) stay fp32 whatever the storage of the
+        # residual stream: they are small (512 channels at 1/8 resolution) and the softmax statistics want them
+        f32 = torch.float32
+        q = self._conv(a.to_q, x, XF_AFFINE, st, out_dtype=f32)
+        k = self._conv(a.to_k, x, XF_AFFINE, st, out_dtype=f32)
+        v = self._conv(a.to_v, x, XF_AFFINE, st, out_dtype=f32)
         qf, kf, vf = q.view(B, T, Cc), k.view(B, T, Cc), v.view(B, T, Cc)
         self._no_hooks(a.to_out[1], "Attention.to_out.1 (dropout)")
         # long sequences (R >= 512): blockwise kernels, online softmax, no T x T tensor; P is recomputed in the backward
@@ -347,7 +358,7 @@ class Engine:
         self._post(a, lambda: x, out)
         if tape is not None:
             def bwd(dout):
-                do = self._conv_bwd(a.to_out[0], o, dout, XF_NONE, None).view(B, T, Cc)
+                do = self._conv_bwd(a.to_out[0], o, dout, XF_NONE, None, dx_dtype=f32).view(B, T, Cc)
                 if blockwise:
                     dq, dk, dv = ops.attn_bwd(saved, of, do, scale)
                 else:
@@ -356,9 +367,9 @@ class Engine:
                     dS = ops.softmax_bwd_rows_(P, dP)
                     dq = ops.gemm_nn(dS, kf, scale)
                     dk = ops.gemm_tn(dS, qf, scale)
-                g = self._conv_bwd(a.to_q, x, dq.view(B, H, W, Cc), XF_AFFINE, st)
-                g = ops.add(g, self._conv_bwd(a.to_k, x, dk.view(B, H, W, Cc), XF_AFFINE, st))
-                g = ops.add(g, self._conv_bwd(a.to_v, x, dv.view(B, H, W, Cc), XF_AFFINE, st))
+                g = self._conv_bwd(a.to_q, x, dq.view(B, H, W, Cc), XF_AFFINE, st, dx_dtype=f32)
+                g = ops.add(g, self._conv_bwd(a.to_k, x, dk.view(B, H, W, Cc), XF_AFFINE, st, dx_dtype=f32))
+                g = ops.add(g, self._conv_bwd(a.to_v, x, dv.view(B, H, W, Cc), XF_AFFINE, st, dx_dtype=f32))
                 dx = self._gn_bwd(a.group_norm, x, g, st, False, dout, feeds_conv3=after_conv3)
                 if notify:
                     self._done(a)
@@ -537,12 +548,12 @@ class Engine:
         if t.shape[-1] == 3:
             t = torch.nn.functional.pad(t, (0, 1))
         with torch.no_grad():
-            return self._conv(m, t, XF_NONE, None).permute(0, 3, 1, 2)
+            return self._conv(m, t, XF_NONE, None, out_dtype=torch.float32).permute(0, 3, 1, 2)
 
     def leaf_linear(self, m, x):
         t = self._standalone(x)
         with torch.no_grad():
-            y = self._conv(m, t, XF_NONE, None)
+            y = self._conv(m, t, XF_NONE, None, out_dtype=torch.float32)
         return y.squeeze(1) if x.ndim == 3 else y.permute(0, 3, 1, 2)
 
     def leaf_groupnorm(self, m, x):
@@ -571,7 +582,7 @@ class Engine:
                 y = self.decoder_nhwc(t, None)
             else:
                 raise NotImplementedError(type(m).__name__)
-        return y.permute(0, 3, 1, 2)
+        return ops.to_f32(y).permute(0, 3, 1, 2)
 
 
 class _EncodeFn(torch.autograd.Function):

@@ -29,7 +29,8 @@ class IgemmArgs(C.Structure):
                 ("xf", C.c_int32), ("alpha", C.c_float), ("prec", C.c_int32), ("Wh", _fp), ("A16", _fp),
                 ("tapmask", C.c_int32), ("a_step", C.c_int32), ("a_oy", C.c_int32), ("a_ox", C.c_int32),
                 ("c_step", C.c_int32), ("c_oy", C.c_int32), ("c_ox", C.c_int32),
-                ("gstat", _fp), ("gstat_groups", C.c_int32), ("Wu", _fp), ("out_bf16", C.c_int32)]
+                ("gstat", _fp), ("gstat_groups", C.c_int32), ("Wu", _fp), ("out_bf16", C.c_int32),
+                ("a_bf16", C.c_int32), ("res_bf16", C.c_int32)]
 
 
 class WgradArgs(C.Structure):
@@ -37,11 +38,12 @@ class WgradArgs(C.Structure):
                 ("g", ConvGeom), ("M", C.c_int32), ("N", C.c_int32), ("ldy", C.c_int32), ("npix", C.c_int32),
                 ("nsplit", C.c_int32), ("batch", C.c_int32), ("sYb", C.c_int64), ("sXb", C.c_int64),
                 ("sOb", C.c_int64), ("xf", C.c_int32), ("alpha", C.c_float), ("prec", C.c_int32), ("X16", _fp), ("dY16", _fp),
-                ("tapmask", C.c_int32), ("y_step", C.c_int32), ("y_oy", C.c_int32), ("y_ox", C.c_int32)]
+                ("tapmask", C.c_int32), ("y_step", C.c_int32), ("y_oy", C.c_int32), ("y_ox", C.c_int32),
+                ("x_bf16", C.c_int32), ("y_bf16", C.c_int32)]
 
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
-EXPECTED_ABI = 9  # vae_abi_version() of the library these structures and signatures describe
+EXPECTED_ABI = 10  # vae_abi_version() of the library these structures and signatures describe
 
 # name -> argtypes (every function returns int); must list EVERY symbol of include/vaehip.h
 SIGNATURES = {
@@ -50,7 +52,10 @@ SIGNATURES = {
     "vae_igemm_rows": [C.POINTER(IgemmArgs), vp],
     "vae_conv_gstat_chunks": [C.POINTER(IgemmArgs)],
     "vae_conv_phase_ok": [C.POINTER(IgemmArgs)],
-    "vae_conv_out_bf16_ok": [C.POINTER(IgemmArgs)],
+    "vae_conv_io16_ok": [C.POINTER(IgemmArgs)],
+    "vae_wgrad_io16_ok": [C.POINTER(WgradArgs)],
+    "vae_add_bf16": [vp, vp, i64, vp, vp],
+    "vae_unpack_bf16": [vp, i64, vp, vp],
     "vae_wino_ok": [C.POINTER(IgemmArgs)],
     "vae_wino_weight_floats": [C.POINTER(IgemmArgs)],
     "vae_wino_weights": [C.POINTER(IgemmArgs), vp, vp],

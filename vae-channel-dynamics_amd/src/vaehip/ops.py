@@ -215,6 +215,37 @@ def _fwd_geom(kind: str, B: int, H: int, W: int, Cs: int) -> ConvGeom:
     raise ValueError(kind)
 
 
+# bf16 mode stores activations as bf16 (round 3): every conv output with at least ACT16_MIN_C channels, the residual stream
+# and the gradients of both -- what autocast keeps for the reference (src/train.py:147-154).  GroupNorm statistics, tracker
+# sums, the loss, the narrow tensors (image, latents, moments) and the parameters stay fp32.  False = fp32 storage with bf16
+# images next to it (round 2's layout; kept for the kernel tests and as the A/B switch).
+ACT_BF16 = True
+ACT16_MIN_C = 32
+
+
+def act16() -> bool:
+    return PRECISION == PREC_BF16 and ACT_BF16 and WEIGHTS16 is not None
+
+
+def to_f32(t: torch.Tensor) -> torch.Tensor:
+    """fp32 copy of a bf16-stored tensor (the tensor itself when it is fp32)"""
+    if t.dtype == torch.float32:
+        return t
+    out = torch.empty(t.shape, device=t.device, dtype=torch.float32)
+    lib.call("vae_unpack_bf16", _p(t.contiguous()), t.numel(), _p(out), _stream())
+    return out
+
+
+def to_bf16(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype == torch.bfloat16:
+        return t
+    return pack_bf16(t.contiguous(), torch.empty(t.shape, device=t.device, dtype=torch.bfloat16))
+
+
+def _like(t: torch.Tensor, want16: bool) -> torch.Tensor:
+    return to_bf16(t) if want16 else to_f32(t)
+
+
 def act_image_ok(kind: str, x_shape, Co: int, Ci: int) -> bool:
     """bf16 mode: may this layer's forward and wgrad read a bf16 image of the transformed input (gn_apply_bf16)?"""
     if PRECISION != PREC_BF16 or WEIGHTS16 is None or kind != "c3":
@@ -240,9 +271,8 @@ def act_image32_ok(kind: str, x_shape, Co: int, Ci: int) -> bool:
     return H % 8 == 0 and W % 16 == 0 and Ci % 32 == 0 and Co % 64 == 0 and Cs == Ci
 
 
-# bf16 mode stores gradients that only feed bf16 kernels as bf16 images (the dgrad outputs of the halo-tile kernels and the
-# GroupNorm-backward outputs): half the bytes in the HBM-bound GroupNorm backward, and the wgrad / dgrad kernels copy them to
-# LDS as they are.  False = fp32 gradients everywhere (the round-1 behaviour).
+# bf16 mode with fp32 storage (ACT_BF16 = False) keeps gradients that only feed bf16 kernels as bf16 images (the dgrad outputs
+# of the halo-tile kernels and the GroupNorm-backward outputs).  False = fp32 gradients everywhere (the round-1 behaviour).
 GRAD_IMAGES = True
 
 
@@ -256,7 +286,7 @@ def grad_image_ok(kind: str, x_shape, Co: int, Ci: int) -> bool:
 
 
 def _grad16(dy: torch.Tensor) -> Optional[torch.Tensor]:
-    """the bf16 image of a gradient tensor: the tensor itself when it is stored as bf16, or the copy its producer attached"""
+    """the bf16 form of a gradient tensor: the tensor itself when it is stored as bf16, or the image its producer attached"""
     if dy.dtype == torch.bfloat16:
         return dy
     return getattr(dy, "_b16", None)
@@ -335,32 +365,42 @@ def _phase_weights(wv):
     return we, we16
 
 
-def _upconv_phase_fwd(x, wv, bias):
-    """-> [B,2H,2W,Co] or None when the halo-tile kernel does not serve the low-resolution geometry"""
+def _upconv_phase_fwd(x, wv, bias, want16: bool):
+    """-> [B,2H,2W,Co] (bf16 when want16 and the kernel can write it) or None when the halo-tile kernels do not serve the
+    low-resolution geometry.  x: fp32, or bf16 (then it IS the operand image)."""
     B, H, W, Cs = x.shape
     Co, _, _, Ci = wv.shape
     if Cs != Ci:
         return None
     a = _phase_args(x.shape, Co, Ci, False)
     a.A, a.W = _p(x), _p(wv)
-    out = torch.empty((B, 2 * H, 2 * W, Co), device=x.device, dtype=torch.float32)
-    a.C, a.bias = _p(out), _p(bias)
+    a.bias = _p(bias)
     a.c_step = 2
     a.Wh = _wh(wv)  # (eligibility of the bf16 kernel: any aligned image will do for the query)
     a.tapmask = _phase_tapmask(0, 0)
+    xb = x.dtype == torch.bfloat16
     x16 = None
     if PRECISION == PREC_BF16 and a.Wh is not None and Cs % 8 == 0:
         # bf16 image of the low-resolution input (a resnet output, no GroupNorm in front): the wide-tile kernel takes the four
         # phase convolutions as 2x2 tap blocks
         a.A16 = a.A  # placeholder with the right alignment for the query
-        if lib.query("vae_conv_phase_ok", C.byref(a)):
-            x16 = pack_bf16(x, torch.empty(x.shape, device=x.device, dtype=torch.bfloat16))
+        a.out_bf16 = 1 if want16 else 0
+        ok = bool(lib.query("vae_conv_phase_ok", C.byref(a)))
+        if ok and want16 and not lib.query("vae_conv_io16_ok", C.byref(a)):
+            a.out_bf16, want16 = 0, False
+        if ok:
+            x16 = x if xb else pack_bf16(x, torch.empty(x.shape, device=x.device, dtype=torch.bfloat16))
             a.A16 = _p(x16)
-            x._b16 = x16  # the layer's weight gradient reads the same image
+            if not xb:
+                x._b16 = x16  # the layer's weight gradient reads the same image
         else:
-            a.A16 = None
-    if x16 is None and not lib.query("vae_conv_phase_ok", C.byref(a)):
-        return None
+            a.A16, a.out_bf16 = None, 0
+    if x16 is None:
+        if xb or not lib.query("vae_conv_phase_ok", C.byref(a)):
+            return None
+        want16 = False
+    out = torch.empty((B, 2 * H, 2 * W, Co), device=x.device, dtype=torch.bfloat16 if want16 else torch.float32)
+    a.C = _p(out)
     we, we16 = _phase_weights(wv)
     for pa in (0, 1):
         for pb in (0, 1):
@@ -371,14 +411,14 @@ def _upconv_phase_fwd(x, wv, bias):
 
 
 def _upconv_phase_dgrad(dy, wv, in_hw, dy16=None):
-    """dy [B,2H,2W,Co] -> gradient wrt the LOW-resolution input [B,H,W,Ci] (no high-resolution intermediate), or None"""
-    B, Hy, Wy, Co = dy.shape
+    """dy [B,2H,2W,Co] (fp32, or None when only the bf16 form dy16 exists) -> gradient wrt the LOW-resolution input
+    [B,H,W,Ci], fp32 (the four phases add up through the residual input), or None when not served"""
+    src = dy if dy is not None else dy16
+    B, Hy, Wy, Co = src.shape
     H, W = in_hw
     _, _, _, Ci = wv.shape
     a = _phase_args((B, H, W, Ci), Co, Ci, True)
-    a.A, a.W = _p(dy), _p(wv)
-    out = torch.empty((B, H, W, Ci), device=dy.device, dtype=torch.float32)
-    a.C = _p(out)
+    a.A, a.W = _p(src), _p(wv)
     a.a_step = 2
     a.Wh = _wh(wv)
     a.tapmask = _phase_tapmask(0, 0)
@@ -392,8 +432,10 @@ def _upconv_phase_dgrad(dy, wv, in_hw, dy16=None):
             a.A16 = _p(dy16)
         else:
             a.A16 = None
-    if not use16 and not lib.query("vae_conv_phase_ok", C.byref(a)):
+    if not use16 and (dy is None or not lib.query("vae_conv_phase_ok", C.byref(a))):
         return None
+    out = torch.empty((B, H, W, Ci), device=src.device, dtype=torch.float32)
+    a.C = _p(out)
     we, we16 = _phase_weights(wv)
     first = True
     for pa in (0, 1):
@@ -406,36 +448,55 @@ def _upconv_phase_dgrad(dy, wv, in_hw, dy16=None):
     return out
 
 
+def _chk_act(t: torch.Tensor, name: str):
+    if not (t.is_cuda and t.dtype in (torch.float32, torch.bfloat16)):
+        raise ValueError(f"{name}: expected a float32 or bfloat16 CUDA tensor, got {t.dtype} on {t.device}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous NHWC tensor, strides {t.stride()}")
+
+
 def conv_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], kind: str, *,
              xf: int = XF_NONE, stats: Optional[Stats] = None, res: Optional[torch.Tensor] = None,
              track: Optional[torch.Tensor] = None, a16: Optional[torch.Tensor] = None,
-             gstat_groups: Optional[int] = None) -> torch.Tensor:
-    """x [B,H,W,Cs] (Cs >= Cin, extra channels must be zero-weighted i.e. Cin is taken from w).
+             gstat_groups: Optional[int] = None, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """x [B,H,W,Cs] (Cs >= Cin, extra channels must be zero-weighted i.e. Cin is taken from w), stored as fp32 or bf16.
     a16: bf16 image of XF(x) (then xf / stats are not applied again; x only gives the geometry).
     gstat_groups: the output feeds a GroupNorm with that many groups: where the kernel has a statistics epilogue the
-    partial sums are attached to the returned tensor (`_gstat`) and gn_stats() on it skips its pass over the tensor."""
-    _chk_c(x, "conv_fwd.x")
+    partial sums are attached to the returned tensor (`_gstat`) and gn_stats() on it skips its pass over the tensor.
+    out_dtype: storage of the result; None = bf16 when bf16 mode stores activations as bf16 (act16()) and the layer has at
+    least ACT16_MIN_C output channels, else fp32.  A kernel that cannot honour the storage of an operand gets fp32 copies."""
+    _chk_act(x, "conv_fwd.x")
+    wv = ohwi(w)
+    Co, kh, kw, Ci = wv.shape
+    want16 = (out_dtype == torch.bfloat16) if out_dtype is not None else (act16() and Co >= ACT16_MIN_C)
     if a16 is not None:
         assert a16.shape == x.shape and a16.dtype == torch.bfloat16 and a16.is_contiguous()
         xf = XF_NONE
     if kind == "c3up" and PHASE_UPCONV and xf == XF_NONE and res is None and track is None and a16 is None:
-        out = _upconv_phase_fwd(x, ohwi(w), bias)
+        out = _upconv_phase_fwd(x, wv, bias, want16)
         if out is not None:
-            return out
-    wv = ohwi(w)
-    Co, kh, kw, Ci = wv.shape
+            return out if (out.dtype == torch.bfloat16) == want16 else _like(out, want16)
     B, H, W, Cs = x.shape
     taps = kh * kw
     assert taps == (1 if kind == "c1" else 9) and Ci <= Cs, (kind, wv.shape, x.shape)
     g = _fwd_geom(kind, B, H, W, Cs)
     if xf != XF_NONE and not lib.query("vae_xf_fusable_rows", C.byref(g), B * g.Ho * g.Wo, Ci):
         x, xf = gn_apply(x, stats, xf), XF_NONE  # tiny spatial size: several batch items per tile
-    out = torch.empty((B, g.Ho, g.Wo, Co), device=x.device, dtype=torch.float32)
     if res is not None:
-        _chk_c(res, "conv_fwd.res")
-        assert res.shape == out.shape
+        _chk_act(res, "conv_fwd.res")
+        assert res.shape == (B, g.Ho, g.Wo, Co)
+        res = _like(res, want16)  # the residual is stored like the output
+    out = torch.empty((B, g.Ho, g.Wo, Co), device=x.device, dtype=torch.bfloat16 if want16 else torch.float32)
     a = IgemmArgs()
     a.A, a.W, a.C, a.bias, a.res = _p(x), _p(wv), _p(out), _p(bias), _p(res)
+    xb = x.dtype == torch.bfloat16
+    if a16 is not None:
+        a.A16 = _p(a16)
+    elif xb and xf == XF_NONE:
+        a.A16 = _p(x)   # a bf16 tensor IS its own image; the dispatcher turns it into a_bf16 for the flat kernels
+    elif xb:
+        a.a_bf16 = 1    # bf16 storage with a transform on load: the flat / <= 4-channel kernels
+    a.out_bf16, a.res_bf16 = int(want16), _b16(res)
     if xf != XF_NONE:
         assert stats is not None and stats.scale.shape == (B, Cs)
         a.scale, a.shift = _p(stats.scale), _p(stats.shift)
@@ -444,9 +505,20 @@ def conv_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], kin
     a.M, a.N, a.K, a.ldc = B * g.Ho * g.Wo, Co, Ci, Co
     a.sn, a.sk, a.st = taps * Ci, 1, Ci
     a.batch, a.sAb, a.sWb, a.sCb = 1, 0, 0, 0
-    a.xf, a.alpha, a.prec, a.Wh, a.A16 = xf, 1.0, PRECISION, _wh(wv), _p(a16)
+    a.xf, a.alpha, a.prec, a.Wh = xf, 1.0, PRECISION, _wh(wv)
     if track is not None:
         assert track.numel() >= ((a.M + 127) // 128) * Co
+    if (a.A16 or a.a_bf16 or a.out_bf16 or a.res_bf16) and not lib.query("vae_conv_io16_ok", C.byref(a)):
+        # the kernel serving this launch takes fp32 storage only (unvectorised shapes, a tracked halo-tile output, ...)
+        x32 = to_f32(a16) if a16 is not None else to_f32(x)
+        y = conv_fwd(x32, w, bias, kind, xf=xf, stats=stats, res=None if res is None else to_f32(res), track=track,
+                     gstat_groups=gstat_groups, out_dtype=torch.float32)
+        if not want16:
+            return y
+        y16 = to_bf16(y)
+        if hasattr(y, "_gstat"):
+            y16._gstat = y._gstat
+        return y16
     wu = _wino(a, x.device)  # (kept alive until the launch is enqueued; the allocator orders its reuse on the stream)
     if gstat_groups and FUSED_GN_STATS:
         a.gstat_groups = int(gstat_groups)
@@ -459,27 +531,28 @@ def conv_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], kin
     return out
 
 
-def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, kind: str, in_hw: Tuple[int, int], out_bf16: bool = False) -> torch.Tensor:
+def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, kind: str, in_hw: Tuple[int, int], out_bf16: bool = False,
+               out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
     """gradient wrt the conv input (the XF'ed tensor); dy [B,Ho,Wo,Co] -> [B,H,W,Ci].
-    dy: fp32 (optionally with a bf16 image attached, `_b16`) or a bf16 tensor; out_bf16: store the result as bf16 when the
-    kernel serving the layer can (the caller feeds it to gn_bwd only) -- otherwise fp32 as ever."""
+    dy: fp32 (optionally with a bf16 image attached, `_b16`) or a bf16 tensor.  Storage of the result: out_dtype, or bf16 when
+    act16() and Ci >= ACT16_MIN_C, or when out_bf16 is asked for and the halo-tile kernel serving the layer can write it (fp32
+    storage mode: the caller feeds it to gn_bwd only), else fp32."""
     dy16 = _grad16(dy)
     dy32 = dy if dy.dtype == torch.float32 else None
-    if dy32 is not None:
-        _chk_c(dy32, "conv_dgrad.dy")
+    _chk_act(dy, "conv_dgrad.dy")
     wv = ohwi(w)
     Co, kh, kw, Ci = wv.shape
     taps = kh * kw
     B, Hy, Wy, Cy = dy.shape
     assert Cy == Co
     H, W = in_hw
-    use16 = dy16 is not None and grad_image_ok(kind, (B, H, W, Ci), Co, Ci)
-    if dy32 is None and not use16:
-        raise ValueError("conv_dgrad: a bf16-only gradient reached a layer whose kernels need fp32")
+    forced = out_dtype is not None
+    want16 = (out_dtype == torch.bfloat16) if forced else (act16() and Ci >= ACT16_MIN_C)
+    use16 = dy16 is not None and (dy32 is None or grad_image_ok(kind, (B, H, W, Ci), Co, Ci))
     if kind == "c3up" and PHASE_UPCONV:
         out = _upconv_phase_dgrad(dy32, wv, in_hw, dy16)
         if out is not None:
-            return out
+            return _like(out, want16)
     if kind == "c3up":
         Hr, Wr, stride, pad = 2 * H, 2 * W, 1, 1
     elif kind == "c3s2":
@@ -501,33 +574,40 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, kind: str, in_hw: Tuple[int, i
     a.sn, a.sk, a.st = 1, taps * Ci, Ci
     a.batch, a.sAb, a.sWb, a.sCb = 1, 0, 0, 0
     a.xf, a.alpha, a.prec, a.Wh = XF_NONE, 1.0, PRECISION, _wh(wv)
+    pool = kind == "c3up"  # (the virtual-upsample fallback: the high-resolution gradient is summed 2x2 in fp32)
     o16 = False
-    if out_bf16 and PRECISION == PREC_BF16 and GRAD_IMAGES and kind == "c3":
+    if not pool and (want16 or (out_bf16 and not forced and PRECISION == PREC_BF16 and GRAD_IMAGES and kind == "c3")):
         a.out_bf16 = 1
         a.C = a.A  # placeholder with the right alignment for the query
-        o16 = bool(lib.query("vae_conv_out_bf16_ok", C.byref(a)))
+        o16 = bool(lib.query("vae_conv_io16_ok", C.byref(a)))
         a.out_bf16 = 1 if o16 else 0
+    if a.A16 and not lib.query("vae_conv_io16_ok", C.byref(a)):  # an fp32-only kernel: hand it an fp32 copy of the gradient
+        return _like(conv_dgrad(to_f32(dy16), w, kind, in_hw, out_dtype=torch.float32), want16)
     out = torch.empty((B, Hr, Wr, Ci), device=src.device, dtype=torch.bfloat16 if o16 else torch.float32)
     a.C = _p(out)
     wu = _wino(a, src.device)
     _launch_igemm(a)
-    if kind == "c3up":
+    if pool:
         pooled = torch.empty((B, H, W, Ci), device=src.device, dtype=torch.float32)
         lib.call("vae_sumpool2x2", _p(out), B, H, W, Ci, _p(pooled), _stream())
-        return pooled
+        out = pooled
+    if want16 and out.dtype != torch.bfloat16:
+        return to_bf16(out)
     return out
 
 
 def _upconv_phase_wgrad(dy, x, gv, bgrad_out, dy16=None) -> bool:
     """weight (and bias) gradient of conv3x3(nearest_upsample_2x(x)) from four phase weight gradients on the low-resolution
     grid (each computes the 4 taps of its 2x2 effective kernel), folded back into the 3x3 gradient; False = not served.
-    bf16 mode: both operands as bf16 images (x at low resolution, dy at high resolution through the strided view)."""
+    bf16 mode: both operands as bf16 images (x at low resolution, dy at high resolution through the strided view); either
+    may be a bf16-stored tensor (dy None: only dy16 exists)."""
     Co, _, _, Ci = gv.shape
     B, H, W, Cs = x.shape
     if Cs != Ci:
         return False
+    xb = x.dtype == torch.bfloat16
     a = WgradArgs()
-    a.dY, a.X = _p(dy), _p(x)
+    a.dY, a.X = _p(dy if dy is not None else dy16), _p(x)
     a.g = ConvGeom(B, H, W, Cs, H, W, 9, 1, 1, 1, MODE_FWD)
     a.M, a.N, a.ldy, a.npix, a.nsplit = Co, Ci, Co, B * H * W, 1
     a.batch, a.sYb, a.sXb, a.sOb = 1, 0, 0, 0
@@ -537,7 +617,7 @@ def _upconv_phase_wgrad(dy, x, gv, bgrad_out, dy16=None) -> bool:
         return False
     keep = []
     if PRECISION == PREC_BF16 and Cs % 8 == 0 and Co % 8 == 0:
-        x16 = getattr(x, "_b16", None)
+        x16 = x if xb else getattr(x, "_b16", None)
         if x16 is None:
             x16 = pack_bf16(x, torch.empty(x.shape, device=x.device, dtype=torch.bfloat16))
         if dy16 is None:
@@ -545,6 +625,8 @@ def _upconv_phase_wgrad(dy, x, gv, bgrad_out, dy16=None) -> bool:
             dy._b16 = dy16  # the dgrad that follows reads the same image
         keep = [x16, dy16]
         a.X16, a.dY16 = _p(x16), _p(dy16)
+    elif xb or dy is None:
+        return False  # the fp32 halo-tile kernel needs fp32 operands
     ns, fus = C.c_int32(0), C.c_int32(0)
     lib.call("vae_wgrad_plan", C.byref(a), C.byref(ns), C.byref(fus))
     ns = ns.value
@@ -600,12 +682,11 @@ def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, kind: str, wgrad_out: torch.Te
                bgrad_out: Optional[torch.Tensor], *, xf: int = XF_NONE, stats: Optional[Stats] = None,
                x16: Optional[torch.Tensor] = None):
     """writes dW into `wgrad_out` (a view with the weight's OHWI memory) and db into `bgrad_out`.
-    x16: bf16 image of XF(x) (as conv_fwd's a16)."""
+    dy and x: fp32 or bf16 tensors; x16: bf16 image of XF(x) (as conv_fwd's a16)."""
     dy16 = _grad16(dy)
     dy32 = dy if dy.dtype == torch.float32 else None
-    if dy32 is not None:
-        _chk_c(dy32, "conv_wgrad.dy")
-    _chk_c(x, "conv_wgrad.x")
+    _chk_act(dy, "conv_wgrad.dy")
+    _chk_act(x, "conv_wgrad.x")
     if x16 is not None:
         assert x16.shape == x.shape and x16.dtype == torch.bfloat16 and x16.is_contiguous()
         xf = XF_NONE
@@ -615,20 +696,24 @@ def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, kind: str, wgrad_out: torch.Te
     B, H, W, Cs = x.shape
     g = _fwd_geom(kind, B, H, W, Cs)
     assert dy.shape == (B, g.Ho, g.Wo, Co), (dy.shape, (B, g.Ho, g.Wo, Co))
-    if (kind == "c3up" and PHASE_UPCONV and xf == XF_NONE and x16 is None and dy32 is not None
-            and _upconv_phase_wgrad(dy32, x, gv, bgrad_out, dy16)):
+    if kind == "c3up" and PHASE_UPCONV and xf == XF_NONE and x16 is None and _upconv_phase_wgrad(dy32, x, gv, bgrad_out, dy16):
         return
     npix = B * g.Ho * g.Wo
-    use16 = dy16 is not None and grad_image_ok(kind, x.shape, Co, Ci)
-    if dy32 is None and not use16:
-        raise ValueError("conv_wgrad: a bf16-only gradient reached a layer whose kernels need fp32")
+    xb = x.dtype == torch.bfloat16
+    use16 = dy16 is not None and (dy32 is None or grad_image_ok(kind, x.shape, Co, Ci))
     a = WgradArgs()
-    a.dY, a.X = _p(dy32), _p(x)
+    a.dY, a.X = _p(dy32 if dy32 is not None else dy16), _p(x)
     a.dY16 = _p(dy16) if use16 else None
     a.g = g
     a.M, a.N, a.ldy, a.npix, a.nsplit = Co, Ci, Co, npix, 1
     a.batch, a.sYb, a.sXb, a.sOb = 1, 0, 0, 0
-    a.xf, a.alpha, a.prec, a.X16 = xf, 1.0, PRECISION, _p(x16)
+    a.xf, a.alpha, a.prec = xf, 1.0, PRECISION
+    if x16 is not None:
+        a.X16 = _p(x16)
+    elif xb and xf == XF_NONE:
+        a.X16 = _p(x)  # a bf16 tensor is its own image (the dispatcher turns it into x_bf16 for the flat kernels)
+    elif xb:
+        a.x_bf16 = 1
     if xf != XF_NONE:
         assert stats is not None
         a.scale, a.shift = _p(stats.scale), _p(stats.shift)
@@ -638,8 +723,12 @@ def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, kind: str, wgrad_out: torch.Te
     lib.call("vae_wgrad_plan", C.byref(a), C.byref(ns), C.byref(fus))
     if xf != XF_NONE and not fus.value:  # tiny spatial size: several batch items per split
         x = gn_apply(x, stats, xf)
-        a.X, a.xf, a.scale, a.shift = _p(x), XF_NONE, None, None
+        a.X, a.xf, a.scale, a.shift, a.x_bf16 = _p(x), XF_NONE, None, None, 0
         lib.call("vae_wgrad_plan", C.byref(a), C.byref(ns), C.byref(fus))
+    if (a.X16 or a.dY16 or a.x_bf16) and not lib.query("vae_wgrad_io16_ok", C.byref(a)):
+        # an fp32-only kernel: fp32 copies of the operands (x16 already holds XF(x))
+        x32 = to_f32(x16) if x16 is not None else to_f32(x)
+        return conv_wgrad(dy32 if dy32 is not None else to_f32(dy16), x32, kind, wgrad_out, bgrad_out, xf=xf, stats=stats)
     ns = ns.value
     a.nsplit = ns
     partial = None
@@ -671,7 +760,7 @@ def _gn_nchunk(B: int, HW: int, Cc: int) -> int:
 
 
 def gn_stats(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, G: int = GN_GROUPS, eps: float = GN_EPS) -> Stats:
-    _chk_c(x, "gn_stats.x")
+    _chk_act(x, "gn_stats.x")
     B, H, W, Cc = x.shape
     HW = H * W
     dev = x.device
@@ -724,20 +813,22 @@ def track_final(ws: torch.Tensor, count: int) -> torch.Tensor:
 def gn_bwd(x: torch.Tensor, g: torch.Tensor, st: Stats, gamma: torch.Tensor, beta: torch.Tensor, silu: bool,
            add: Optional[torch.Tensor], dgamma: torch.Tensor, dbeta: torch.Tensor, G: int = GN_GROUPS,
            want32: bool = True, want16: bool = False) -> torch.Tensor:
-    """g: fp32 or bf16 (a dgrad output stored as bf16).  Returns dx as fp32 (want32; with the bf16 image attached as `_b16`
-    when want16 too) or as a bf16 tensor alone (want16 only: a gradient that feeds bf16 convolution kernels and nothing else)."""
-    _chk_c(x, "gn_bwd.x")
+    """x: the GroupNorm input as stored (fp32 or bf16); g: fp32 or bf16; add (the residual-path gradient) is brought to x's
+    storage.  Returns dx as fp32 (want32; with the bf16 image attached as `_b16` when want16 too) or as a bf16 tensor alone
+    (want16 only: bf16 storage mode, or a gradient that feeds bf16 convolution kernels and nothing else)."""
+    _chk_act(x, "gn_bwd.x")
     g16 = g.dtype == torch.bfloat16
-    if not g16:
-        _chk_c(g, "gn_bwd.g")
-    assert g.is_contiguous() and g.shape == x.shape and (add is None or add.shape == x.shape) and (want32 or want16)
+    _chk_act(g, "gn_bwd.g")
+    assert g.shape == x.shape and (add is None or add.shape == x.shape) and (want32 or want16)
+    if add is not None:
+        add = _like(add.contiguous(), x.dtype == torch.bfloat16)
     B, H, W, Cc = x.shape
     HW = H * W
     nch = _gn_nchunk(B, HW, Cc)
     dev = x.device
     ws = torch.empty((B, nch, Cc, 2), device=dev, dtype=torch.float32)
     coef = torch.empty((B, G, 2), device=dev, dtype=torch.float32)
-    dx = torch.empty_like(x) if want32 else None
+    dx = torch.empty(x.shape, device=dev, dtype=torch.float32) if want32 else None
     dx16 = torch.empty(x.shape, device=dev, dtype=torch.bfloat16) if want16 else None
     s = _stream()
     lib.call("vae_gn_bwd_partial", _p(x), _b16(x), _p(g), _p(st.mean), _p(st.rstd), _p(gamma), _p(beta), B, HW, Cc, G, nch,
@@ -917,6 +1008,12 @@ def mse_bwd(recon: torch.Tensor, target: torch.Tensor, scale: float = 1.0) -> to
 
 
 def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a + b; two bf16 tensors (or a mixed pair, brought to bf16) give a bf16 sum rounded once from the fp32 sum"""
+    if a.dtype == torch.bfloat16 or b.dtype == torch.bfloat16:
+        a, b = to_bf16(a), to_bf16(b)
+        o = torch.empty_like(a)
+        lib.call("vae_add_bf16", _p(a), _p(b), a.numel(), _p(o), _stream())
+        return o
     o = torch.empty_like(a)
     lib.call("vae_add", _p(a), _p(b), a.numel(), _p(o), _stream())
     return o
