@@ -81,7 +81,7 @@ def host_cpu_share():
     return n, f"{n} threads (affinity {aff} logical CPUs, cgroup quota {quota if quota else 'none'}, host physical cores {phys if phys else 'unknown'}; capped at 16)"
 
 
-def cpu_baseline(batch: int = 2, max_seconds: float = 55.0):
+def cpu_baseline(batch: int = 4, max_seconds: float = 55.0):
     """reference-equivalent CPU path (PyTorch oracle) on the host cores: full train steps (fwd+loss+bwd+clip+AdamW, 3 tracker
     hooks) on a bounded sample of the same workload.  Thread count fixed explicitly (host_cpu_share); one untimed warm-up
     step at the SAME shape, then timed steps while the budget lasts (at least one, at most three); every step time is
@@ -147,7 +147,7 @@ def workload_label(dtype: str, R: int, B: int, ckpt: bool, nudge: int, tracking:
     else:
         idx = {256: 2, 512: 3, 1024: 4}.get(R)
     head = f"BASELINE configs[{idx}]" if idx is not None else "off-baseline shape"
-    prec = "fp32" if dtype == "f32" else "bf16 MFMA compute (fp32 accumulate, fp32 master weights and statistics)"
+    prec = "fp32" if dtype == "f32" else "bf16 MFMA compute (fp32 accumulate, fp32 master weights and statistics; activations stored as bf16)"
     extra = (", decoder activation-checkpointed" if ckpt else "") + (f", gentle nudge every {nudge} steps" if nudge else ", no nudge")
     return (f"{head}: SDXL-VAE {R}x{R} synthetic RGB, batch {B}/GPU, {prec}, "
             f"tracking {'on (3 layers) + classifier' if tracking else 'off'}{extra}; random-init weights (synthetic:42)")
@@ -161,8 +161,11 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="per-GPU batch (default = BASELINE config)")
     ap.add_argument("--res", type=int, default=RES)
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
-                    help="f32 = BASELINE configs[1] (the metric); bf16 = configs[2]-style compute (bf16 MFMA, fp32 accumulate/storage)")
+                    help="f32 = BASELINE configs[1] (the metric); bf16 = configs[2]-style compute (bf16 MFMA, fp32 accumulate, bf16 activation storage)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--act-fp32", action="store_true",
+                    help="bf16 mode A/B switch: keep activations and their gradients as fp32 tensors with bf16 images beside them (round 2's "
+                         "layout) instead of storing them as bf16")
     ap.add_argument("--no-tracking", action="store_true", help="A/B switch for the tracker-overhead measurement")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP-event timing")
     ap.add_argument("--nudge-interval", type=int, default=0,
@@ -219,6 +222,8 @@ def main():
     from vaehip.trainer import HipTrainer
     from vaehip import ops
 
+    if args.act_fp32:
+        ops.ACT_BF16 = False
     torch.manual_seed(42)
     w = SDXLVAEWrapper("synthetic:42", device=dev)
     trainer = HipTrainer(w, lr=1e-5, max_grad_norm=1.0, kl_weight=1e-6, lr_warmup_steps=100,

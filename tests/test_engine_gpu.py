@@ -12,7 +12,9 @@ TRACKED = ["encoder.conv_in", "encoder.down_blocks.0.resnets.0.norm1", "decoder.
 
 
 # 2x the worst per-tensor gradient error measured on MI355X (filled from profiles/r03_parity_measured.json)
-GRAD_TOL = {(32, 2): 5e-4, (64, 2): 5e-4, (40, 1): 5e-4, (48, 3): 5e-4}
+# measured worst per case, over the three fp32 paths (Winograd + activation image, Winograd fused, direct kernels):
+# R=32 2.5e-5, R=64 2.3e-5, R=40 3.6e-5, R=48 2.8e-5 -- every tensor inside north_star's 1e-4
+GRAD_TOL = {(32, 2): 5.0e-5, (64, 2): 4.6e-5, (40, 1): 7.2e-5, (48, 3): 5.6e-5}
 
 
 def ops_mod():
