@@ -7,6 +7,10 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_f32 -o k -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-profile > $O/stats_f32.json 2> $O/stats_f32.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_bf16 -o k -- python3 $R/bench.py --dtype bf16 --steps 4 --warmup 2 --no-cpu-baseline --no-profile > $O/stats_bf16.json 2> $O/stats_bf16.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_dead -o k -- python3 $R/tools/dead_scan_bench.py > $O/dead_scan.json 2> $O/dead_scan.err
+# BASELINE configs[2] per-GPU shape, configs[3] (512^2, nudge in the loop) and configs[4] (1024^2, decoder checkpointed, blockwise attention)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_bf16_b32 -o k -- python3 $R/bench.py --dtype bf16 --batch 32 --steps 3 --warmup 2 --no-cpu-baseline --no-profile > $O/stats_bf16_b32.json 2> $O/stats_bf16_b32.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_bf16_512 -o k -- python3 $R/bench.py --dtype bf16 --res 512 --batch 8 --nudge-interval 100 --steps 3 --warmup 2 --no-cpu-baseline --no-profile > $O/stats_bf16_512.json 2> $O/stats_bf16_512.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_bf16_1024 -o k -- python3 $R/bench.py --dtype bf16 --res 1024 --batch 2 --checkpoint-decoder --steps 3 --warmup 2 --no-cpu-baseline --no-profile > $O/stats_bf16_1024.json 2> $O/stats_bf16_1024.err
 for P in f32 bf16; do
   for C in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/pmc_${P}_$C -- python3 $R/bench.py --dtype $P --steps 1 --warmup 1 --no-cpu-baseline --no-profile > $O/pmc_${P}_$C.json 2> $O/pmc_${P}_$C.err
@@ -16,5 +20,5 @@ cd $R
 python3 tools/hbm_traffic.py $O/pmc_f32_FETCH_SIZE $O/pmc_f32_WRITE_SIZE $O/hbm_traffic_f32.json $COMMIT
 python3 tools/hbm_traffic.py $O/pmc_bf16_FETCH_SIZE $O/pmc_bf16_WRITE_SIZE $O/hbm_traffic_bf16.json $COMMIT
 # keep the merged-back volume small: the raw counter CSVs are large
-rm -rf $O/pmc_*_SIZE/*/ 2>/dev/null; find $O -name "*_kernel_trace.csv" -size +20M -delete
+rm -rf $O/pmc_*_SIZE/*/ 2>/dev/null; find $O -name "*_kernel_trace.csv" -delete; find $O -name "*_agent_info.csv" -delete
 ls -la $O

@@ -226,11 +226,52 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_rows_bf16_kernel(vae_igemm
   float tsum[NI];
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) tsum[ni] = 0.f;
+  // bf16 output with an even column count (and a bf16 residual or none): adjacent lanes hold adjacent columns of the same 16
+  // rows; they swap every other register, so a lane stores BOTH columns of its pair for 8 rows -- 4-byte stores and 4-byte
+  // residual loads instead of 2-byte ones (the 2-byte form cost the flat kernels 20 % when bf16 storage came in)
+  const bool pair16 = cbf && (p.N % 2 == 0) && (p.ldc % 2 == 0) && (p.res == nullptr || rbf) && p.track == nullptr &&
+                      ((reinterpret_cast<uintptr_t>(C) & 3u) == 0);
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
     const int col = n0 + wn * TN + ni * 32 + lr;
     const bool colok = col < p.N;
     const float bv = (p.bias && colok) ? p.bias[col] : 0.f;
+    if (pair16) {  // uniform
+      const bool odd = lr & 1;
+      const float b0 = (p.bias && colok) ? p.bias[col & ~1] : 0.f, b1 = (p.bias && colok) ? p.bias[col | 1] : 0.f;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        unsigned o16[8], rr[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int r = 2 * j + (odd ? 1 : 0);
+          const int row = m0 + wm * TM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          int orow = row;
+          if (s2c) {
+            int b, y, x;
+            row_pixel(row < p.M ? row : m0, b, y, x);
+            orow = (b * g.Ho + y) * g.Wo + x;
+          }
+          o16[j] = (colok && row < p.M) ? (unsigned)(orow * p.ldc + (col & ~1)) * 2u : BUF_OOB;
+          rr[j] = 0u;
+        }
+        if (p.res) {  // uniform
+#pragma unroll
+          for (int j = 0; j < 8; ++j) rr[j] = __builtin_amdgcn_raw_buffer_load_b32(rsR, o16[j], 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float a0 = p.alpha * acc[mi][ni][2 * j], a1 = p.alpha * acc[mi][ni][2 * j + 1];
+          const float recv = __shfl_xor(odd ? a0 : a1, 1, 64);
+          typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+          bf16x2_t h;
+          h[0] = (__bf16)((odd ? recv : a0) + b0 + __builtin_bit_cast(float, rr[j] << 16));
+          h[1] = (__bf16)((odd ? a1 : recv) + b1 + __builtin_bit_cast(float, rr[j] & 0xffff0000u));
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, h), rsC, o16[j], 0, 0);
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       int off[16];
