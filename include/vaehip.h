@@ -65,6 +65,9 @@ int vae_get_option(const char* name);
                              * enumerated PARITY-CLASS-major: m = ((cls*B + b)*Ho/2 + i)*Wo/2 + j, pixel (2i+cls/2, 2j+cls%2).
                              * A class only meets the taps of its parity (4, 2, 2 or 1 of the 9), so no masked work;
                              * needs B*Ho*Wo/4 % 128 == 0 (class-uniform tiles).  Output rows are written at the pixel. */
+#define VAE_MODE_UP2X_DGRAD 4 /* gradient wrt the LOW-resolution input of conv3x3(nearest_upsample_2x(x)): source = the
+                             * HIGH-resolution dY (Hs = 2 Ho, Ws = 2 Wo), row grid = the low-resolution pixels; the 3x3 dgrad and the
+                             * 2x2 sum-pool in one pass.  Only the fp32 Winograd-type kernel implements it (vae_wino_ok, Wu). */
 
 typedef struct vae_conv_geom {
   int32_t B, Hs, Ws, Cs; /* source tensor [B][Hs][Ws][Cs]                         */

@@ -915,3 +915,41 @@ def test_winograd_wgrad(cuda, B, H, W, Ci, Co):
     assert _rel(gw0, dw0) < 2e-5 and _rel(gw1, dw1) < 2e-5 and _rel(gb0, db0) < 1e-5 and not torch.equal(gw0, dw0)
     g2, _ = run(ops.XF_NONE)  # deterministic
     assert torch.equal(g2, gw0)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Upsampler convolution conv3x3(nearest_upsample_2x(x)) in fp32 with 9 multiplications per low-resolution pixel and channel pair
+# (csrc/conv3_upwino.hip, csrc/wgrad3_upwino.hip): forward, dgrad (3x3 dgrad + 2x2 sum-pool in one pass) and wgrad against
+# torch's interpolate + conv2d and autograd, and against the phase-convolution path (library option "no_wino").
+# (3,4,8,512,64): one tile per image, 64 chunk steps; (2,12,24,128,160): N not a multiple of 64; (1,32,32,128,128): 32 tiles
+# ---------------------------------------------------------------------------------------------------------
+UPWINO_CASES = [(2, 8, 16, 128, 128), (1, 16, 32, 256, 128), (3, 4, 8, 512, 64), (2, 12, 24, 128, 160), (1, 32, 32, 128, 128)]
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co", UPWINO_CASES)
+def test_upsampler_winograd_forward_and_dgrad(cuda, B, H, W, Ci, Co):
+    from vaehip import ops
+    gen = torch.Generator().manual_seed(51 + Ci + Co + H)
+    x = torch.randn(B, Ci, H, W, generator=gen) * 1.3 + 0.2
+    w = torch.randn(Co, Ci, 3, 3, generator=gen) / math.sqrt(9 * Ci)
+    bias = torch.randn(Co, generator=gen)
+    dy = torch.randn(B, Co, 2 * H, 2 * W, generator=gen)
+    xd, wd = _nhwc(x), _to_dev_ohwi(w)
+    prof = ops.PROFILER = ops.LaunchProfiler()
+    try:
+        y = ops.conv_fwd(xd, wd, bias.cuda(), "c3up")
+        dx = ops.conv_dgrad(_nhwc(dy), wd, "c3up", (H, W))
+    finally:
+        ops.PROFILER = None
+    assert [r[0] for r in prof.records] == ["conv3_upwino_kernel<false>", "conv3_upwino_kernel<true>"], [r[0] for r in prof.records]
+    assert all(r[2] * 4 == r[1] for r in prof.records)  # 9 of 36 multiplications executed
+    xr = x.clone().requires_grad_(True)
+    ref = F.conv2d(F.interpolate(xr, scale_factor=2.0, mode="nearest"), w, bias, 1, 1)
+    (gx,) = torch.autograd.grad(ref, xr, dy)
+    assert y.shape == (B, 2 * H, 2 * W, Co) and _rel(_nchw(y), ref.detach()) < 1e-5 and _rel(_nchw(dx), gx) < 1e-5
+    with ops.option("no_wino"):  # the four phase convolutions on the direct kernels
+        z = ops.conv_fwd(xd, wd, bias.cuda(), "c3up")
+        dz = ops.conv_dgrad(_nhwc(dy), wd, "c3up", (H, W))
+    assert _rel(y, z) < 5e-6 and _rel(dx, dz) < 5e-6 and not torch.equal(y, z)
+    assert torch.equal(ops.conv_fwd(xd, wd, bias.cuda(), "c3up"), y)  # deterministic
+

@@ -24,14 +24,17 @@ __device__ __forceinline__ f32x4 unpack4(uint2 r) {
   v[3] = __builtin_bit_cast(float, r.y & 0xffff0000u);
   return v;
 }
-// 4 consecutive elements of an operand stored as fp32 (16-byte load) or bf16 (8-byte load) through a buffer descriptor whose
-// range is in BYTES of that storage; `eoff` = ELEMENT offset of the quad, or a negative value for "out of range" (reads zeros)
-__device__ __forceinline__ f32x4 buf_load4_elems(__amdgpu_buffer_rsrc_t rs, bool bf, int eoff) {
-  if (bf) {
-    const unsigned off = eoff >= 0 ? (unsigned)eoff * 2u : BUF_OOB;
-    return unpack4(__builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0)));
-  }
-  return VAE_BUF_LOAD4(rs, eoff >= 0 ? (unsigned)eoff * 4u : BUF_OOB);
+// 4 consecutive elements of an operand stored as fp32 or bf16, through a buffer descriptor whose range is in BYTES of that
+// storage.  ONE instruction for both storages -- a 16-byte load at element offset `eoff` (a bf16 operand's load also brings the
+// next 4 elements along, unused) -- and the conversion happens where the value is CONSUMED (raw4_to_f32 at the LDS write a
+// pipeline step later).  A storage-dependent load instruction plus an immediate conversion had made hipcc wait for every load
+// right behind it (the flat kernels lost 20 % when bf16 storage came in).  eoff < 0 = out of range (reads zeros).
+__device__ __forceinline__ uint4 buf_load4_raw(__amdgpu_buffer_rsrc_t rs, unsigned esize, int eoff) {
+  return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, eoff >= 0 ? (unsigned)eoff * esize : BUF_OOB, 0, 0));
+}
+__device__ __forceinline__ f32x4 raw4_to_f32(uint4 r, bool bf) {
+  if (bf) return unpack4(uint2{r.x, r.y});
+  return __builtin_bit_cast(f32x4, r);
 }
 // one element through a descriptor (fp32: 4-byte, bf16: 2-byte access); eoff < 0 = out of range
 __device__ __forceinline__ float buf_load1_elem(__amdgpu_buffer_rsrc_t rs, bool bf, int eoff) {

@@ -26,6 +26,9 @@ bool conv3_wino_eligible(const vae_igemm_args& a);                      // conv3
 int launch_wino_weights(const vae_igemm_args& a, float* U, hipStream_t st);
 int launch_conv3_wino(const vae_igemm_args& a, const float* U, hipStream_t st);
 int conv3_wino_gstat_chunks(const vae_igemm_args& a);
+bool conv3_upwino_eligible(const vae_igemm_args& a);                    // conv3_upwino.hip (fp32 upsampler convolution, 9 positions)
+int launch_upwino_weights(const vae_igemm_args& a, float* U, hipStream_t st);
+int launch_conv3_upwino(const vae_igemm_args& a, const float* U, hipStream_t st);
 int conv3_wino_nb();
 bool conv3_wide_bf16_eligible(const vae_igemm_args& a);                 // conv3_wide_bf16.hip (both operands bf16 images, 8x32 tiles)
 int conv3_wide_bf16_gstat_chunks(const vae_igemm_args& a);
@@ -649,7 +652,9 @@ int check_geom(const char* who, const vae_conv_geom& g) {
   VAE_CHECK(g.B > 0 && g.Hs > 0 && g.Ws > 0 && g.Cs > 0 && g.Ho > 0 && g.Wo > 0, "%s: non-positive geometry", who);
   VAE_CHECK(g.taps == 1 || g.taps == 9, "%s: taps must be 1 or 9 (got %d)", who, g.taps);
   VAE_CHECK(g.stride == 1 || g.stride == 2, "%s: stride must be 1 or 2", who);
-  VAE_CHECK(g.mode >= 0 && g.mode <= 3, "%s: bad mode", who);
+  VAE_CHECK(g.mode >= 0 && g.mode <= 4, "%s: bad mode", who);
+  VAE_CHECK(g.mode != VAE_MODE_UP2X_DGRAD || (g.taps == 9 && g.stride == 1 && g.Hs == 2 * g.Ho && g.Ws == 2 * g.Wo),
+            "%s: UP2X_DGRAD needs 3x3 stride 1, source twice the row grid", who);
   VAE_CHECK(g.mode != VAE_MODE_DGRAD_S2 ||
                 (g.taps == 9 && g.stride == 2 && g.pad_t == 0 && g.pad_l == 0 && g.Ho % 2 == 0 && g.Wo % 2 == 0 &&
                  ((int64_t)g.B * g.Ho * g.Wo / 4) % 128 == 0),
@@ -809,10 +814,22 @@ static bool rows_wino(const vae_igemm_args& a) {
   return conv3_wino_eligible(a) && rows_vec(a, bkm) && !conv_smallk_eligible(a) && !conv_smalln_eligible(a) && !vae_opt().flat_conv &&
          !vae_opt().no_wino;
 }
-extern "C" int vae_wino_ok(const vae_igemm_args* ap) { return (ap && rows_wino(*ap)) ? 1 : 0; }
-extern "C" int64_t vae_wino_weight_floats(const vae_igemm_args* ap) { return ap ? (int64_t)16 * ap->N * ap->K : 0; }
+// the upsampler convolution (forward over the virtual nearest-2x upsample, or its dgrad with the 2x2 sum-pool folded in) as the
+// 9-position scheme of conv3_upwino.hip
+static bool rows_upwino(const vae_igemm_args& a) { return conv3_upwino_eligible(a) && !vae_opt().flat_conv && !vae_opt().no_wino; }
+extern "C" int vae_wino_ok(const vae_igemm_args* ap) { return (ap && (rows_wino(*ap) || rows_upwino(*ap))) ? 1 : 0; }
+extern "C" int64_t vae_wino_weight_floats(const vae_igemm_args* ap) {
+  if (!ap) return 0;
+  const bool up = ap->g.mode == VAE_MODE_UP2X || ap->g.mode == VAE_MODE_UP2X_DGRAD;
+  return (int64_t)(up ? 9 : 16) * ap->N * ap->K;
+}
 extern "C" int vae_wino_weights(const vae_igemm_args* ap, float* Wu, void* stream) {
   VAE_CHECK(ap && Wu && ap->W && aligned16(Wu), "wino_weights: null or unaligned pointer");
+  if (rows_upwino(*ap)) {
+    if (int rc = launch_upwino_weights(*ap, Wu, (hipStream_t)stream)) return rc;
+    VAE_LAUNCH_CHECK("upwino_weights");
+    return VAE_OK;
+  }
   VAE_CHECK(rows_wino(*ap), "wino_weights: the layer is not served by the Winograd kernel (vae_wino_ok)");
   if (int rc = launch_wino_weights(*ap, Wu, (hipStream_t)stream)) return rc;
   VAE_LAUNCH_CHECK("wino_weights");
@@ -884,7 +901,9 @@ extern "C" int vae_igemm_kernel_name(const vae_igemm_args* ap, char* buf, int32_
   const vae_igemm_args a = rows_canon(*ap);
   const bool bkm = rows_bkm(a), vec = rows_vec(a, bkm);
   const char* tf[2] = {"false", "true"};
-  if (a.Wu != nullptr && rows_wino(a))
+  if (a.Wu != nullptr && rows_upwino(a))
+    snprintf(buf, n, "conv3_upwino_kernel<%s>", tf[a.g.mode == VAE_MODE_UP2X_DGRAD]);
+  else if (a.Wu != nullptr && rows_wino(a))
     snprintf(buf, n, "conv3_wino_kernel<%d,%d>", a.xf, conv3_wino_nb());
   else if (rows_is_phase(a) && rows_use_wide_bf16(a, vec, bkm))
     snprintf(buf, n, "conv3_wide_bf16_kernel<%s,2>", tf[a.g.mode == VAE_MODE_DGRAD]);
@@ -950,6 +969,13 @@ extern "C" int vae_igemm_rows(const vae_igemm_args* ap, void* stream) {
   VAE_CHECK(a.gstat == nullptr || vae_conv_gstat_chunks(ap) > 0, "igemm_rows: no statistics epilogue for these arguments (vae_conv_gstat_chunks)");
   VAE_CHECK(rows_io16_ok(a), "igemm_rows: the kernel serving these arguments does not take this combination of out_bf16 / a_bf16 / res_bf16 (vae_conv_io16_ok)");
   hipStream_t st = (hipStream_t)stream;
+  VAE_CHECK(a.g.mode != VAE_MODE_UP2X_DGRAD || a.Wu != nullptr, "igemm_rows: UP2X_DGRAD exists only as the Winograd-type kernel (vae_wino_ok, Wu)");
+  if (a.Wu != nullptr && rows_upwino(a)) {  // the upsampler convolution with ITS transformed weights (9 positions)
+    VAE_CHECK(aligned16(a.Wu), "igemm_rows: unaligned Wu");
+    if (int rc2 = launch_conv3_upwino(a, a.Wu, st)) return rc2;
+    VAE_LAUNCH_CHECK("conv3_upwino");
+    return VAE_OK;
+  }
   if (a.Wu != nullptr) {  // Winograd F(2x2,3x3) with the transformed weights the caller built for THIS geometry
     VAE_CHECK(rows_wino(a) && aligned16(a.Wu), "igemm_rows: Wu needs a layer vae_wino_ok accepts");
     if (int rc2 = launch_conv3_wino(a, a.Wu, st)) return rc2;

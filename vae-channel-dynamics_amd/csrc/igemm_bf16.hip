@@ -108,7 +108,8 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_rows_bf16_kernel(vae_igemm
 
   const int kchunks = (p.K + BK - 1) / BK;
   const int steps = ntaps * kchunks;
-  f32x4 ra[AR], rw[BR];
+  uint4 ra[AR];  // A as loaded (fp32 quad, or 4 bf16 in the low half): converted at the LDS write
+  f32x4 rw[BR];
   int a_b[AR];
   int reg_c0 = 0;
 
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_rows_bf16_kernel(vae_igemm
     for (int i = 0; i < AR; ++i) {
       int sy = 0, sx = 0;
       const bool ok = src_pixel(g, ry[i], rx[i], kh, kw, sy, sx) && (rb[i] >= 0);
-      ra[i] = buf_load4_elems(rsA, abf, (ok && c < p.K) ? (((rb[i] - b_base) * g.Hs + sy) * g.Ws + sx) * g.Cs + c : -1);
+      ra[i] = buf_load4_raw(rsA, esA, (ok && c < p.K) ? (((rb[i] - b_base) * g.Hs + sy) * g.Ws + sx) * g.Cs + c : -1);
       a_b[i] = ok ? rb[i] : -1;
     }
     if (!BKM) {
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_rows_bf16_kernel(vae_igemm
     const int c = reg_c0 + k4 * 4;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
-      f32x4 v = ra[i];
+      f32x4 v = raw4_to_f32(ra[i], abf);
       if (XF != VAE_XF_NONE) {
         const bool ok = (a_b[i] >= 0) && (c < p.K);
         const int o = ok ? (a_b[i] - b_lo) * p.K + c : 0;
@@ -385,7 +386,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_bf16_kernel(vae_wgrad_args
 
   const int a4 = tid % AQ, akq = tid / AQ;
   const int b4 = tid % BQ, bkq = tid / BQ;
-  f32x4 ra[AI], rx[BI];
+  uint4 ra[AI], rx[BI];  // as loaded: converted at the LDS write
   int xb[BI];
   f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
 
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_bf16_kernel(vae_wgrad_args
     for (int i = 0; i < AI; ++i) {
       const int pix = pb + akq + AKR * i;
       const int c = m0 + a4 * 4;
-      ra[i] = buf_load4_elems(rsY, ybf, (pix < pend && c < p.M) ? (pix - pbeg) * p.ldy + c : -1);
+      ra[i] = buf_load4_raw(rsY, esY, (pix < pend && c < p.M) ? (pix - pbeg) * p.ldy + c : -1);
     }
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
@@ -405,19 +406,20 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_bf16_kernel(vae_wgrad_args
       const int y = rem / g.Wo, x = rem - y * g.Wo;
       int sy = 0, sx = 0;
       const bool ok = src_pixel(g, y, x, kh, kw, sy, sx) && (pix < pend);
-      rx[i] = buf_load4_elems(rsX, xbf, (ok && c < p.N) ? (((b - b_lo) * g.Hs + sy) * g.Ws + sx) * g.Cs + c : -1);
+      rx[i] = buf_load4_raw(rsX, esX, (ok && c < p.N) ? (((b - b_lo) * g.Hs + sy) * g.Ws + sx) * g.Cs + c : -1);
       xb[i] = ok ? b : -1;
     }
   };
   auto store_lds = [&](u16* sA, u16* sB) {
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-      *reinterpret_cast<uint2*>(&sA[(akq + AKR * i) * LDA + a4 * 4]) = pack4(ra[i]);
-      if (do_bias) bsum += ra[i];
+      const f32x4 v = raw4_to_f32(ra[i], ybf);
+      *reinterpret_cast<uint2*>(&sA[(akq + AKR * i) * LDA + a4 * 4]) = ybf ? uint2{ra[i].x, ra[i].y} : pack4(v);
+      if (do_bias) bsum += v;
     }
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
-      f32x4 v = rx[i];
+      f32x4 v = raw4_to_f32(rx[i], xbf);
       if (XF != VAE_XF_NONE) {
         const bool ok = xb[i] >= 0;
         const int o = ok ? (xb[i] - b_lo) * BN + b4 * 4 : 0;

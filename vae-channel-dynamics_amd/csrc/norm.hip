@@ -108,12 +108,16 @@ __global__ __launch_bounds__(256) void gn_stats_final_kernel(const float* __rest
   __shared__ double sS[256], sQ[256], sMean[64];
   const int b = blockIdx.x;
   // ws[b][chunk][g] = (mean, M2) of chunk `chunk` (pixels [chunk*per, min(HW, (chunk+1)*per)) x the group's channels; a conv
-  // epilogue leaves one chunk per output tile: hundreds).  Chan's merge in fp64: first the count-weighted mean, then
-  // M2 = sum_k M2_k + n_k (mean_k - mean)^2.  The chunk range is dealt out to 256 / G threads per group, fixed order.
-  const int parts = 256 / G;  // G <= 64
+  // epilogue leaves one chunk per output tile: hundreds to thousands).  Chan's merge in fp64: first the count-weighted mean, then
+  // M2 = sum_k M2_k + n_k (mean_k - mean)^2.  Workgroup (b, y) finishes groups [y*gw, (y+1)*gw), gw = G / gridDim.y; the chunk
+  // range of a group is dealt out to 256 / gw threads, fixed order (round 3: with one workgroup per image and 8 threads per
+  // group the 4096 chunks of a 1024^2 image took 17 us x 400 launches per step).
+  const int gw = G / (int)gridDim.y, g0 = (int)blockIdx.y * gw;
+  const int parts = 256 / gw;  // gw <= 64
   const int per = (HW + nchunk - 1) / nchunk;
   const int cpg_ = C / G;
-  const int g_ = threadIdx.x % G, part_ = threadIdx.x / G;
+  const int gl = threadIdx.x % gw, part_ = threadIdx.x / gw;
+  const int g_ = g0 + gl;
   {
     double S = 0.0;
     if (part_ < parts)
@@ -125,46 +129,46 @@ __global__ __launch_bounds__(256) void gn_stats_final_kernel(const float* __rest
     sS[threadIdx.x] = S;
   }
   __syncthreads();
-  if (threadIdx.x < G) {
+  if (threadIdx.x < gw) {
     double S = 0.0;
-    for (int part = 0; part < parts; ++part) S += sS[part * G + threadIdx.x];
+    for (int part = 0; part < parts; ++part) S += sS[part * gw + threadIdx.x];
     sMean[threadIdx.x] = S / ((double)HW * (double)cpg_);
   }
   __syncthreads();
   {
-    const double m = sMean[g_];
+    const double m = sMean[gl];
     double Q = 0.0;
     if (part_ < parts)
       for (int c = part_; c < nchunk; c += parts) {
         const float* o = ws + (((int64_t)b * nchunk + c) * G + g_) * 2;
-        const double nk = (double)max(0, min(HW, (c + 1) * per) - c * per) * (double)cpg_;  // trailing chunks can start beyond HW: empty
+        const double nk = (double)max(0, min(HW, (c + 1) * per) - c * per) * (double)cpg_;
         const double d = (double)o[0] - m;
         Q += (double)o[1] + nk * d * d;
       }
     sQ[threadIdx.x] = Q;
   }
   __syncthreads();
-  if (threadIdx.x < G) {
-    const int g = threadIdx.x;
+  if (threadIdx.x < gw) {
+    const int g = g0 + threadIdx.x;
     double Q = 0.0;
-    for (int part = 0; part < parts; ++part) Q += sQ[part * G + g];
+    for (int part = 0; part < parts; ++part) Q += sQ[part * gw + threadIdx.x];
     const double n = (double)HW * (double)(C / G);
-    const double m = sMean[g];
+    const double m = sMean[threadIdx.x];
     double var = Q / n;
     if (var < 0.0) var = 0.0;
     const float mf = (float)m, rf = (float)(1.0 / sqrt(var + (double)eps));
-    smean[g] = mf;
-    srstd[g] = rf;
+    smean[threadIdx.x] = mf;
+    srstd[threadIdx.x] = rf;
     mean[b * G + g] = mf;
     rstd[b * G + g] = rf;
   }
   __syncthreads();
   const int cpg = C / G;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    const int g = c / cpg;
-    const float sc = srstd[g] * gamma[c];
+  for (int cl = threadIdx.x; cl < gw * cpg; cl += 256) {
+    const int c = g0 * cpg + cl;
+    const float sc = srstd[cl / cpg] * gamma[c];
     scale[(int64_t)b * C + c] = sc;
-    shift[(int64_t)b * C + c] = beta[c] - smean[g] * sc;
+    shift[(int64_t)b * C + c] = beta[c] - smean[cl / cpg] * sc;
   }
 }
 
@@ -348,35 +352,52 @@ __device__ __forceinline__ void gn_bwd_dparam_role(const float* __restrict__ ws,
   }
 }
 
-// stage 2a: one workgroup per batch item: chunk totals per (b,c) and the group coefficients
+// stage 2a: workgroup (b, group block gb): chunk totals per (b, c) and the group coefficients of groups [gb*GPW, (gb+1)*GPW).
+// The block's channels (GPW * cpg <= 64) each get 256 / (GPW * cpg) threads that split the chunk range (thread t of a channel
+// takes chunks t, t + T, ...), fp64, then thread 0 of the channel adds the T partial sums in order: a fixed association.
+// (Round 3: with one workgroup per image and a serial loop over 512 chunks the launch took 40-200 us at batch 2.)
+constexpr int GN_GPW = 4;  // groups per workgroup of stage 2a
 __global__ __launch_bounds__(256) void gn_bwd_final_kernel(const float* __restrict__ ws, const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma, int B, int HW, int C, int G,
                                                            int nchunk, float* __restrict__ coef, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta) {
-  __shared__ __attribute__((aligned(16))) float sg1[1024];
-  __shared__ float sg2[1024];
-  if ((int)blockIdx.x >= B) {  // uniform per workgroup
-    gn_bwd_dparam_role(ws, blockIdx.x - B, B, C, nchunk, dgamma, dbeta, reinterpret_cast<double*>(sg1));  // 512 doubles = sizeof(sg1)
+  __shared__ __attribute__((aligned(16))) double sred[2][256];
+  __shared__ float sg1[64], sg2[64];
+  const int cpg = C / G;
+  const int gblocks = G / GN_GPW, nwa = B * gblocks;
+  if ((int)blockIdx.x >= nwa) {  // uniform per workgroup
+    gn_bwd_dparam_role(ws, blockIdx.x - nwa, B, C, nchunk, dgamma, dbeta, &sred[0][0]);  // 512 doubles
     return;
   }
-  const int cpg = C / G;
-  const int b = blockIdx.x;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    double a1 = 0.0, a2 = 0.0;
-    for (int k = 0; k < nchunk; ++k) {
-      const float* o = ws + (((int64_t)b * nchunk + k) * C + c) * 2;
-      a1 += (double)o[0];
-      a2 += (double)o[1];
+  const int b = blockIdx.x / gblocks, gb = blockIdx.x % gblocks;
+  const int nc = GN_GPW * cpg;           // channels of the block: 16, 32 or 64
+  const int T = 256 / nc;                // threads per channel
+  const int cl = threadIdx.x % nc, part = threadIdx.x / nc;
+  const int c = gb * nc + cl;
+  double a1 = 0.0, a2 = 0.0;
+  for (int k = part; k < nchunk; k += T) {
+    const float* o = ws + (((int64_t)b * nchunk + k) * C + c) * 2;
+    a1 += (double)o[0];
+    a2 += (double)o[1];
+  }
+  sred[0][threadIdx.x] = a1;
+  sred[1][threadIdx.x] = a2;
+  __syncthreads();
+  if (part == 0) {
+    for (int j = 1; j < T; ++j) {
+      a1 += sred[0][j * nc + cl];
+      a2 += sred[1][j * nc + cl];
     }
-    sg1[c] = (float)(a1 * (double)gamma[c]);
-    sg2[c] = (float)(a2 * (double)gamma[c]);
+    sg1[cl] = (float)(a1 * (double)gamma[c]);
+    sg2[cl] = (float)(a2 * (double)gamma[c]);
   }
   __syncthreads();
-  for (int g = threadIdx.x; g < G; g += 256) {
+  if (threadIdx.x < GN_GPW) {
+    const int g = gb * GN_GPW + threadIdx.x;
     double s1 = 0.0, s2 = 0.0;
     for (int j = 0; j < cpg; ++j) {
-      s1 += (double)sg1[g * cpg + j];
-      s2 += (double)sg2[g * cpg + j];
+      s1 += (double)sg1[threadIdx.x * cpg + j];
+      s2 += (double)sg2[threadIdx.x * cpg + j];
     }
     const double n = (double)HW * (double)cpg;
     const double r = (double)rstd[b * G + g];
@@ -452,7 +473,9 @@ extern "C" int vae_gn_stats_final(const float* ws, int32_t B, int32_t HW, int32_
                                   float* scale, float* shift, void* stream) {
   if (int e = check_gn("gn_stats_final", B, HW, C, G, nchunk)) return e;
   VAE_CHECK(ws && gamma && beta && mean && rstd && scale && shift, "gn_stats_final: null pointer");
-  hipLaunchKernelGGL(gn_stats_final_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, ws, HW, C, G, nchunk, gamma, beta,
+  // few images with many chunks each (large feature maps at small batch): several workgroups per image
+  const int gy = (nchunk >= 256 && G % 8 == 0 && B < 64) ? 8 : 1;
+  hipLaunchKernelGGL(gn_stats_final_kernel, dim3(B, gy), dim3(256), 0, (hipStream_t)stream, ws, HW, C, G, nchunk, gamma, beta,
                      eps, mean, rstd, scale, shift);
   VAE_LAUNCH_CHECK("gn_stats_final");
   return VAE_OK;
@@ -523,8 +546,8 @@ extern "C" int vae_gn_bwd_final(const float* ws, const float* rstd, const float*
                                 int32_t G, int32_t nchunk, float* dgamma, float* dbeta, float* coef, void* stream) {
   if (int e = check_gn("gn_bwd_final", B, HW, C, G, nchunk)) return e;
   VAE_CHECK(ws && rstd && gamma && dgamma && dbeta && coef, "gn_bwd_final: null pointer");
-  VAE_CHECK(C <= 1024, "gn_bwd_final: C > 1024");
-  hipLaunchKernelGGL(gn_bwd_final_kernel, dim3(B + (C + 7) / 8), dim3(256), 0, (hipStream_t)stream, ws, rstd, gamma, B, HW, C, G,
+  VAE_CHECK(G % GN_GPW == 0 && GN_GPW * (C / G) <= 64 && 256 % (GN_GPW * (C / G)) == 0, "gn_bwd_final: %d channels per group unsupported (G=%d)", C / G, G);
+  hipLaunchKernelGGL(gn_bwd_final_kernel, dim3(B * (G / GN_GPW) + (C + 7) / 8), dim3(256), 0, (hipStream_t)stream, ws, rstd, gamma, B, HW, C, G,
                      nchunk, coef, dgamma, dbeta);
   VAE_LAUNCH_CHECK("gn_bwd_final");
   return VAE_OK;

@@ -274,7 +274,7 @@ __global__ __launch_bounds__(NNT) void conv_smalln_kernel(vae_igemm_args p, int 
 
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   const int hk4 = tid & 7;  // the thread's 4 channels are the same for all of its halo slots
-  f32x4 rh[NHI];
+  uint4 rh[NHI];  // as loaded (fp32 quad or 4 bf16): converted when the halo is stored
   int hmask = 0;
   f32x4 rsc = {0.f, 0.f, 0.f, 0.f}, rsh = {0.f, 0.f, 0.f, 0.f};
   auto load_halo = [&](int c0) {
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(NNT) void conv_smalln_kernel(vae_igemm_args p, int 
       const int ir = pp / NHW, jc = pp - ir * NHW;
       const int hy = y0 - 1 + ir, hx = x0 - 1 + jc;
       const bool ok = (q < NHQ) && ((unsigned)hy < (unsigned)g.Hs) && ((unsigned)hx < (unsigned)g.Ws) && (c < p.K);
-      rh[i] = buf_load4_elems(rsA, abf, ok ? ((hy * g.Ws + hx) * g.Cs + c) : -1);
+      rh[i] = buf_load4_raw(rsA, esA, ok ? ((hy * g.Ws + hx) * g.Cs + c) : -1);
       hmask |= (ok ? 1 : 0) << i;
     }
   };
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(NNT) void conv_smalln_kernel(vae_igemm_args p, int 
     for (int i = 0; i < NHI; ++i) {
       const int q = tid + NNT * i;
       if (q < NHQ) {
-        f32x4 v = rh[i];
+        f32x4 v = raw4_to_f32(rh[i], abf);
         if (XF != VAE_XF_NONE) {  // padding must stay zero after the transform
           const bool ok = (hmask >> i) & 1;
 #pragma unroll

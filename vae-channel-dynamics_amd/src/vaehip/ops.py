@@ -77,7 +77,7 @@ def get_option(name: str) -> int:
     return int(lib.query("vae_get_option", name.encode()))
 
 
-MODE_FWD, MODE_UP2X, MODE_DGRAD, MODE_DGRAD_S2 = 0, 1, 2, 3
+MODE_FWD, MODE_UP2X, MODE_DGRAD, MODE_DGRAD_S2, MODE_UP2X_DGRAD = 0, 1, 2, 3, 4
 GN_GROUPS = 32
 GN_EPS = 1e-6
 
@@ -137,6 +137,10 @@ def _launch_igemm(a: IgemmArgs):
     ex_taps = bin(a.tapmask).count("1") if a.tapmask else taps
     name = _kernel_name("vae_igemm_kernel_name", a)
     base = 2.0 * a.M * a.N * a.K * a.batch
+    if "upwino" in name:  # conv3x3 over the virtual 2x upsample: 36 multiply-adds per low-resolution pixel and channel pair, 9 executed
+        lowres = a.M / 4.0 if a.g.mode == MODE_UP2X else float(a.M)
+        _timed(name, 2.0 * lowres * a.N * a.K * 36, 2.0 * lowres * a.N * a.K * 9, "vae_igemm_rows", C.byref(a), _stream())
+        return
     _timed(name, base * taps, base * ex_taps * (WINO_EXECUTED if "wino" in name else 1.0), "vae_igemm_rows", C.byref(a), _stream())
 
 
@@ -365,6 +369,50 @@ def _phase_weights(wv):
     return we, we16
 
 
+def _upconv_wino_fwd(x, wv, bias):
+    """fp32: conv3x3(nearest_upsample_2x(x)) with 9 multiplications per low-resolution pixel and channel pair
+    (csrc/conv3_upwino.hip) -> [B,2H,2W,Co], or None when the kernel does not serve the layer"""
+    if not WINOGRAD or PRECISION != PREC_F32 or x.dtype != torch.float32:
+        return None
+    B, H, W, Cs = x.shape
+    Co, _, _, Ci = wv.shape
+    a = IgemmArgs()
+    a.g = ConvGeom(B, H, W, Cs, 2 * H, 2 * W, 9, 1, 1, 1, MODE_UP2X)
+    a.M, a.N, a.K, a.ldc = B * 4 * H * W, Co, Ci, Co
+    a.sn, a.sk, a.st = 9 * Ci, 1, Ci
+    a.batch, a.sAb, a.sWb, a.sCb = 1, 0, 0, 0
+    a.xf, a.alpha, a.prec = XF_NONE, 1.0, PRECISION
+    out = torch.empty((B, 2 * H, 2 * W, Co), device=x.device, dtype=torch.float32)
+    a.A, a.W, a.C, a.bias = _p(x), _p(wv), _p(out), _p(bias)
+    wu = _wino(a, x.device)
+    if wu is None:
+        return None
+    _launch_igemm(a)
+    return out
+
+
+def _upconv_wino_dgrad(dy, wv, in_hw):
+    """fp32: dy [B,2H,2W,Co] -> gradient wrt the low-resolution input [B,H,W,Ci] (3x3 dgrad + 2x2 sum-pool in one pass), or None"""
+    if not WINOGRAD or PRECISION != PREC_F32 or dy is None or dy.dtype != torch.float32:
+        return None
+    B, Hy, Wy, Co = dy.shape
+    H, W = in_hw
+    _, _, _, Ci = wv.shape
+    a = IgemmArgs()
+    a.g = ConvGeom(B, Hy, Wy, Co, H, W, 9, 1, 1, 1, MODE_UP2X_DGRAD)
+    a.M, a.N, a.K, a.ldc = B * H * W, Ci, Co, Ci
+    a.sn, a.sk, a.st = 1, 9 * Ci, Ci
+    a.batch, a.sAb, a.sWb, a.sCb = 1, 0, 0, 0
+    a.xf, a.alpha, a.prec = XF_NONE, 1.0, PRECISION
+    out = torch.empty((B, H, W, Ci), device=dy.device, dtype=torch.float32)
+    a.A, a.W, a.C = _p(dy), _p(wv), _p(out)
+    wu = _wino(a, dy.device)
+    if wu is None:
+        return None
+    _launch_igemm(a)
+    return out
+
+
 def _upconv_phase_fwd(x, wv, bias, want16: bool):
     """-> [B,2H,2W,Co] (bf16 when want16 and the kernel can write it) or None when the halo-tile kernels do not serve the
     low-resolution geometry.  x: fp32, or bf16 (then it IS the operand image)."""
@@ -472,6 +520,10 @@ def conv_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], kin
     if a16 is not None:
         assert a16.shape == x.shape and a16.dtype == torch.bfloat16 and a16.is_contiguous()
         xf = XF_NONE
+    if kind == "c3up" and xf == XF_NONE and res is None and track is None and a16 is None and not want16:
+        out = _upconv_wino_fwd(x, wv, bias)
+        if out is not None:
+            return out
     if kind == "c3up" and PHASE_UPCONV and xf == XF_NONE and res is None and track is None and a16 is None:
         out = _upconv_phase_fwd(x, wv, bias, want16)
         if out is not None:
@@ -549,6 +601,10 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, kind: str, in_hw: Tuple[int, i
     forced = out_dtype is not None
     want16 = (out_dtype == torch.bfloat16) if forced else (act16() and Ci >= ACT16_MIN_C)
     use16 = dy16 is not None and (dy32 is None or grad_image_ok(kind, (B, H, W, Ci), Co, Ci))
+    if kind == "c3up" and not want16:
+        out = _upconv_wino_dgrad(dy32, wv, in_hw)
+        if out is not None:
+            return out
     if kind == "c3up" and PHASE_UPCONV:
         out = _upconv_phase_dgrad(dy32, wv, in_hw, dy16)
         if out is not None:
