@@ -179,7 +179,7 @@ typedef struct vae_wgrad_args {
                            * the <= 4-channel kernels (vae_wgrad_io16_ok); the halo-tile kernel takes images through X16 / dY16 */
 } vae_wgrad_args;
 int vae_wgrad(const vae_wgrad_args* a, void* stream);
-/* Winograd F(3x3,2x2) weight gradient of plain 3x3 stride-1 layers in fp32 (csrc/wgrad3_wino.hip; 2.25x fewer multiplications
+/* Winograd F(3x3,2x2) weight gradient of plain 3x3 stride-1 layers (and, with 9 positions, of upsampler convolutions) in fp32 (csrc/wgrad3_wino.hip; 2.25x fewer multiplications
  * than vae_wgrad).  vae_wgrad_wino_plan: *nsplit = 0 when the layer `a` describes is not served, else the split count to use;
  * vae_wgrad_wino: a->partial receives the transform-domain slab [nsplit][16][Cin][Cout] (a->out unused), a->bias_partial
  * (optional) [nsplit][Cout] as in vae_wgrad; vae_wgrad_wino_reduce: fixed-order sum over the splits (into scratch
@@ -187,8 +187,12 @@ int vae_wgrad(const vae_wgrad_args* a, void* stream);
  * db [Cout].  Replaces the same reference call as vae_wgrad.                                                              */
 int vae_wgrad_wino_plan(const vae_wgrad_args* a, int32_t* nsplit);
 int vae_wgrad_wino(const vae_wgrad_args* a, void* stream);
-int vae_wgrad_wino_reduce(const float* slab, int32_t nsplit, int32_t Cin, int32_t Cout, float* scratch, float* dW,
+int vae_wgrad_wino_reduce(const float* slab, int32_t nsplit, int32_t npos, int32_t Cin, int32_t Cout, float* scratch, float* dW,
                           const float* bias_partial, float* db, void* stream);
+/* positions of the transform domain the kernel serving `a` accumulates: 16 (plain 3x3 stride-1 layer), or 9 for the convolution
+ * of an Upsample2D block (a->g.mode == VAE_MODE_UP2X: rows and columns of the upsampled patch repeat in pairs, csrc/wgrad3_upwino.hip);
+ * the slab is [nsplit][npos][Cin][Cout] and npos goes to vae_wgrad_wino_reduce                                                   */
+int vae_wgrad_wino_positions(const vae_wgrad_args* a);
 /* 1 when the kernel serving `a` honours a->x_bf16 / a->y_bf16 as they are set */
 int vae_wgrad_io16_ok(const vae_wgrad_args* a);
 /* 1 when the kernel serving `a` honours tapmask / y_step.. (the fp32 halo-tile wgrad kernel)                       */

@@ -566,12 +566,13 @@ def test_upconv_phase_decomposition(cuda):
             assert _rel(F.conv2d(x, wp, None, 1, 1), y_ref[:, :, pa::2, pb::2]) < 2e-6
     prof = ops.PROFILER = ops.LaunchProfiler()
     try:
-        y = ops.conv_fwd(_nhwc(x), _to_dev_ohwi(w), None, "c3up")
-        dy = torch.randn(B, Co, 2 * H, 2 * W, generator=gen)
-        dx = ops.conv_dgrad(_nhwc(dy), _to_dev_ohwi(w), "c3up", (H, W))
-        gw = torch.full_like(_to_dev_ohwi(w).permute(0, 2, 3, 1).contiguous(), float("nan")).permute(0, 3, 1, 2)
-        gb = torch.full((Co,), float("nan"), device="cuda")
-        ops.conv_wgrad(_nhwc(dy), _nhwc(x), "c3up", gw, gb)
+        with ops.option("no_wino"):  # (round 3: the default fp32 path of the upsampler is the 9-position scheme, tested below)
+            y = ops.conv_fwd(_nhwc(x), _to_dev_ohwi(w), None, "c3up")
+            dy = torch.randn(B, Co, 2 * H, 2 * W, generator=gen)
+            dx = ops.conv_dgrad(_nhwc(dy), _to_dev_ohwi(w), "c3up", (H, W))
+            gw = torch.full_like(_to_dev_ohwi(w).permute(0, 2, 3, 1).contiguous(), float("nan")).permute(0, 3, 1, 2)
+            gb = torch.full((Co,), float("nan"), device="cuda")
+            ops.conv_wgrad(_nhwc(dy), _nhwc(x), "c3up", gw, gb)
     finally:
         ops.PROFILER = None
     assert len(prof.records) == 12 and all(r[0].startswith("conv3_tile_kernel") for r in prof.records[:8])
@@ -952,4 +953,34 @@ def test_upsampler_winograd_forward_and_dgrad(cuda, B, H, W, Ci, Co):
         dz = ops.conv_dgrad(_nhwc(dy), wd, "c3up", (H, W))
     assert _rel(y, z) < 5e-6 and _rel(dx, dz) < 5e-6 and not torch.equal(y, z)
     assert torch.equal(ops.conv_fwd(xd, wd, bias.cuda(), "c3up"), y)  # deterministic
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 8, 16, 128, 128), (1, 16, 32, 256, 64), (3, 4, 8, 512, 128), (5, 6, 24, 128, 192), (1, 1, 8, 128, 64)])
+def test_upsampler_winograd_wgrad(cuda, B, H, W, Ci, Co):
+    """(5,6,24,...): several strips per row, images per split; (1,1,8,...): a single unit"""
+    from vaehip import ops
+    gen = torch.Generator().manual_seed(61 + Ci + Co + H)
+    x = torch.randn(B, Ci, H, W, generator=gen) * 1.3 + 0.2
+    w = torch.randn(Co, Ci, 3, 3, generator=gen, requires_grad=True)
+    dy = torch.randn(B, Co, 2 * H, 2 * W, generator=gen)
+    xd, dyd = _nhwc(x), _nhwc(dy)
+
+    def run():
+        gw = torch.full((Co, 3, 3, Ci), float("nan"), device="cuda").permute(0, 3, 1, 2)
+        gb = torch.full((Co,), float("nan"), device="cuda")
+        ops.conv_wgrad(dyd, xd, "c3up", gw, gb)
+        return gw, gb
+    prof = ops.PROFILER = ops.LaunchProfiler()
+    try:
+        gw, gb = run()
+    finally:
+        ops.PROFILER = None
+    assert [r[0] for r in prof.records if r[1] > 0] == ["wgrad3_upwino_kernel"], [r[0] for r in prof.records]
+    F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, None, 1, 1).backward(dy)
+    assert _rel(gw.cpu(), w.grad) < 2e-5 and _rel(gb.cpu(), dy.sum(dim=(0, 2, 3))) < 1e-5
+    with ops.option("no_wino"):
+        dw, db = run()
+    assert _rel(gw, dw) < 2e-5 and _rel(gb, db) < 1e-5 and not torch.equal(gw, dw)
+    g2, _ = run()  # deterministic
+    assert torch.equal(g2, gw)
 

@@ -180,9 +180,12 @@ __global__ __launch_bounds__(UNT, 2) void conv3_upwino_kernel(vae_igemm_args p, 
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[nb][e] = 0.f;
 
-  // prologue: halo(0), halo(1) in LDS, V(0) from halo(0); halo(2) and the U fragments of step 0 in registers
-  f32x4 bq0[UNB], bq1[UNB];
+  // prologue: halo(0), halo(1) in LDS, V(0) from halo(0); halo(2) and the U fragments of steps 0 and 1 in registers.  THREE
+  // register sets carry the U stream: a step here is 8 MFMAs per wave (~0.5 us for the workgroup), shorter than an L2 round trip
+  // under load, so the fragments of step s+2 are requested during step s (one step of lead left the matrix pipe at 0.46)
+  f32x4 bq0[UNB], bq1[UNB], bq2[UNB];
   load_b(0, bq0);
+  load_b(1, bq1);
   {
     f32x4 h0, h1;
     load_halo_into(0, h0);
@@ -205,9 +208,9 @@ __global__ __launch_bounds__(UNT, 2) void conv3_upwino_kernel(vae_igemm_args p, 
     store_halo_from(sH + par * USH, rh);                                       // halo(s+2)
     load_halo_into(s + 3, rh);
   };
-  auto step = [&](int s, int par, const f32x4 (&cur)[UNB], f32x4 (&nxt)[UNB]) {
+  auto step = [&](int s, int par, const f32x4 (&cur)[UNB], f32x4 (&nxt)[UNB]) {  // nxt: the set step s-1 used, receives step s+2
     const float* cV = sV + par * USV;
-    load_b(s + 1, nxt);
+    load_b(s + 2, nxt);
     __builtin_amdgcn_sched_barrier(0);
     if (wave < 4) {  // uniform per wave: the waves that own the V transform stage first, the others multiply first
       stage_next(s, par);
@@ -222,13 +225,11 @@ __global__ __launch_bounds__(UNT, 2) void conv3_upwino_kernel(vae_igemm_args p, 
     }
     __syncthreads();
   };
-  {
-    int s = 0;
-    for (; s + 1 < nsteps; s += 2) {
-      step(s, 0, bq0, bq1);
-      step(s + 1, 1, bq1, bq0);
-    }
-    if (s < nsteps) step(s, 0, bq0, bq1);
+  for (int s = 0; s < nsteps; ++s) {  // step s multiplies set s % 3 and refills set (s + 2) % 3
+    const int par = s & 1, r3 = s % 3;
+    if (r3 == 0) step(s, par, bq0, bq2);
+    else if (r3 == 1) step(s, par, bq1, bq0);
+    else step(s, par, bq2, bq1);
   }
 
   // ---- epilogue: per 32-channel block, M through LDS, then the output transform ----

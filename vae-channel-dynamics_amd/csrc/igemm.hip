@@ -41,6 +41,10 @@ bool wgrad3_wino_eligible(const vae_wgrad_args& a);
 int64_t wgrad3_wino_units(const vae_conv_geom& g);
 int launch_wgrad3_wino(const vae_wgrad_args& a, hipStream_t st);
 int launch_wino_wgrad_reduce(const float* slab, int nsplit, int N, int M, float* dW, const float* bpart, float* db, hipStream_t st);
+bool wgrad3_upwino_eligible(const vae_wgrad_args& a);                   // wgrad3_upwino.hip (fp32 upsampler convolution, 9 positions)
+int64_t wgrad3_upwino_units(const vae_conv_geom& g);
+int launch_wgrad3_upwino(const vae_wgrad_args& a, hipStream_t st);
+int launch_upwino_wgrad_reduce(const float* slab, int nsplit, int N, int M, float* dW, const float* bpart, float* db, hipStream_t st);
 bool wgrad3_tile_bf16_eligible(const vae_wgrad_args& a, bool vec);
 int64_t wgrad3_tile_bf16_units(const vae_conv_geom& g);
 int wgrad3_tile_bf16_columns(const vae_wgrad_args& a);
@@ -1045,7 +1049,14 @@ extern "C" int vae_igemm_rows(const vae_igemm_args* ap, void* stream) {
 extern "C" int vae_wgrad_wino_plan(const vae_wgrad_args* ap, int32_t* nsplit) {
   VAE_CHECK(ap && nsplit, "wgrad_wino_plan: null argument");
   *nsplit = 0;
-  if (!wgrad3_wino_eligible(*ap) || vae_opt().flat_conv || vae_opt().no_wino) return VAE_OK;
+  if (vae_opt().flat_conv || vae_opt().no_wino) return VAE_OK;
+  if (wgrad3_upwino_eligible(*ap)) {  // the upsampler convolution: 9 positions, two 9-wave workgroups per CU
+    const int64_t units = wgrad3_upwino_units(ap->g);
+    const int64_t wgs = (int64_t)(ap->M / 64) * (ap->N / 32);
+    *nsplit = (int32_t)std::max<int64_t>(1, std::min<int64_t>(512 / std::max<int64_t>(wgs, 1), units / 8));
+    return VAE_OK;
+  }
+  if (!wgrad3_wino_eligible(*ap)) return VAE_OK;
   const int64_t units = wgrad3_wino_units(ap->g);
   const int64_t wgs = (int64_t)(ap->M / 128) * (ap->N / 32);
   *nsplit = (int32_t)std::max<int64_t>(1, std::min<int64_t>(256 / std::max<int64_t>(wgs, 1), units / 8));  // one 8-wave workgroup per CU
@@ -1056,9 +1067,14 @@ extern "C" int vae_wgrad_wino(const vae_wgrad_args* ap, void* stream) {
   const vae_wgrad_args& a = *ap;
   if (int e = check_geom("wgrad_wino", a.g)) return e;
   VAE_CHECK(a.dY && a.X && a.partial, "wgrad_wino: null operand");
-  VAE_CHECK(wgrad3_wino_eligible(a), "wgrad_wino: the layer is not served by the Winograd kernel (vae_wgrad_wino_plan)");
   VAE_CHECK(a.nsplit > 0 && a.nsplit <= 65535, "wgrad_wino: bad nsplit");
   VAE_CHECK((int64_t)a.g.B * a.g.Ho * a.g.Wo == a.npix && a.N <= a.g.Cs && a.ldy >= a.M, "wgrad_wino: inconsistent sizes");
+  if (wgrad3_upwino_eligible(a)) {
+    if (int rc = launch_wgrad3_upwino(a, (hipStream_t)stream)) return rc;
+    VAE_LAUNCH_CHECK("wgrad3_upwino");
+    return VAE_OK;
+  }
+  VAE_CHECK(wgrad3_wino_eligible(a), "wgrad_wino: the layer is not served by the Winograd kernel (vae_wgrad_wino_plan)");
   VAE_CHECK(a.xf == VAE_XF_NONE || (a.scale && a.shift), "wgrad_wino: xf needs scale/shift");
   if (int rc = launch_wgrad3_wino(a, (hipStream_t)stream)) return rc;
   VAE_LAUNCH_CHECK("wgrad3_wino");
@@ -1066,18 +1082,20 @@ extern "C" int vae_wgrad_wino(const vae_wgrad_args* ap, void* stream) {
 }
 static int reduce_splits_impl(const float* partial, int32_t nsplit, int64_t n, float* out, const float* partial2, int32_t n2, float* out2,
                               hipStream_t st);
-extern "C" int vae_wgrad_wino_reduce(const float* slab, int32_t nsplit, int32_t Cin, int32_t Cout, float* scratch, float* dW,
+extern "C" int vae_wgrad_wino_positions(const vae_wgrad_args* ap) { return (ap && wgrad3_upwino_eligible(*ap)) ? 9 : 16; }
+extern "C" int vae_wgrad_wino_reduce(const float* slab, int32_t nsplit, int32_t npos, int32_t Cin, int32_t Cout, float* scratch, float* dW,
                                      const float* bias_partial, float* db, void* stream) {
   VAE_CHECK(slab && dW && nsplit > 0 && Cin > 0 && Cout > 0 && Cin % 32 == 0 && Cout % 32 == 0, "wgrad_wino_reduce: bad args");
+  VAE_CHECK(npos == 16 || npos == 9, "wgrad_wino_reduce: npos must be 16 (plain 3x3 layer) or 9 (upsampler convolution)");
   VAE_CHECK((bias_partial == nullptr) == (db == nullptr), "wgrad_wino_reduce: bias_partial and db go together");
   VAE_CHECK(nsplit == 1 || scratch != nullptr, "wgrad_wino_reduce: nsplit > 1 needs the [16*Cin*Cout] scratch buffer");
   hipStream_t st = (hipStream_t)stream;
   if (nsplit > 1) {  // wide fixed-order sum over the splits first (the slab of a 128-channel layer is 64 x 1 MB), then the transform
-    if (int rc = reduce_splits_impl(slab, nsplit, (int64_t)16 * Cin * Cout, scratch, bias_partial, bias_partial ? Cout : 0, db, st)) return rc;
+    if (int rc = reduce_splits_impl(slab, nsplit, (int64_t)npos * Cin * Cout, scratch, bias_partial, bias_partial ? Cout : 0, db, st)) return rc;
     VAE_LAUNCH_CHECK("reduce_splits");
-    if (int rc = launch_wino_wgrad_reduce(scratch, 1, Cin, Cout, dW, nullptr, nullptr, st)) return rc;
+    if (int rc = (npos == 9 ? launch_upwino_wgrad_reduce : launch_wino_wgrad_reduce)(scratch, 1, Cin, Cout, dW, nullptr, nullptr, st)) return rc;
   } else {
-    if (int rc = launch_wino_wgrad_reduce(slab, 1, Cin, Cout, dW, bias_partial, db, st)) return rc;
+    if (int rc = (npos == 9 ? launch_upwino_wgrad_reduce : launch_wino_wgrad_reduce)(slab, 1, Cin, Cout, dW, bias_partial, db, st)) return rc;
   }
   VAE_LAUNCH_CHECK("wino_wgrad_reduce");
   return VAE_OK;

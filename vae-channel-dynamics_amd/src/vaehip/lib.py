@@ -64,7 +64,8 @@ SIGNATURES = {
     "vae_wgrad_phase_ok": [C.POINTER(WgradArgs)],
     "vae_wgrad_wino_plan": [C.POINTER(WgradArgs), C.POINTER(i32)],
     "vae_wgrad_wino": [C.POINTER(WgradArgs), vp],
-    "vae_wgrad_wino_reduce": [vp, i32, i32, i32, vp, vp, vp, vp, vp],
+    "vae_wgrad_wino_reduce": [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp],
+    "vae_wgrad_wino_positions": [C.POINTER(WgradArgs)],
     "vae_upconv_fold_wgrad": [vp, vp, i32, i32, vp, vp, vp],
     "vae_wgrad": [C.POINTER(WgradArgs), vp],
     "vae_xf_fusable_rows": [C.POINTER(ConvGeom), i32, i32],

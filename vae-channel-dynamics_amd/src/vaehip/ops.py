@@ -723,13 +723,17 @@ def _wgrad_wino(a: WgradArgs, gv: torch.Tensor, bgrad_out: Optional[torch.Tensor
     ns = ns.value
     if ns <= 0:
         return False
-    slab = torch.empty((ns, 16 * a.N * a.M), device=dev, dtype=torch.float32)
+    npos = int(lib.query("vae_wgrad_wino_positions", C.byref(a)))  # 16, or 9 for an upsampler convolution
+    slab = torch.empty((ns, npos * a.N * a.M), device=dev, dtype=torch.float32)
     bpart = torch.empty((ns, a.M), device=dev, dtype=torch.float32) if bgrad_out is not None else None
     a.nsplit, a.partial, a.bias_partial = ns, _p(slab), _p(bpart)
-    fl = 2.0 * a.M * a.N * a.npix * 9
-    _timed(f"wgrad3_wino_kernel<{a.xf}>", fl, fl * WINO_EXECUTED, "vae_wgrad_wino", C.byref(a), _stream())
-    scratch = torch.empty((16 * a.N * a.M,), device=dev, dtype=torch.float32) if ns > 1 else None
-    _timed("wgrad_wino_reduce (split sum + output transform)", 0.0, 0.0, "vae_wgrad_wino_reduce", _p(slab), ns, a.N, a.M,
+    fl = 2.0 * a.M * a.N * a.npix * 9  # (npix = output pixels: the direct convolution's count in both cases)
+    if npos == 9:
+        _timed("wgrad3_upwino_kernel", fl, fl * 0.25, "vae_wgrad_wino", C.byref(a), _stream())
+    else:
+        _timed(f"wgrad3_wino_kernel<{a.xf}>", fl, fl * WINO_EXECUTED, "vae_wgrad_wino", C.byref(a), _stream())
+    scratch = torch.empty((npos * a.N * a.M,), device=dev, dtype=torch.float32) if ns > 1 else None
+    _timed("wgrad_wino_reduce (split sum + output transform)", 0.0, 0.0, "vae_wgrad_wino_reduce", _p(slab), ns, npos, a.N, a.M,
            _p(scratch), _p(gv), _p(bpart), _p(bgrad_out), _stream())
     return True
 
@@ -752,6 +756,15 @@ def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, kind: str, wgrad_out: torch.Te
     B, H, W, Cs = x.shape
     g = _fwd_geom(kind, B, H, W, Cs)
     assert dy.shape == (B, g.Ho, g.Wo, Co), (dy.shape, (B, g.Ho, g.Wo, Co))
+    if (kind == "c3up" and PRECISION == PREC_F32 and WINOGRAD and xf == XF_NONE and x16 is None and dy32 is not None
+            and x.dtype == torch.float32):
+        a = WgradArgs()  # the 9-position scheme of csrc/wgrad3_upwino.hip (fp32)
+        a.dY, a.X, a.g = _p(dy32), _p(x), g
+        a.M, a.N, a.ldy, a.npix, a.nsplit = Co, Ci, Co, B * g.Ho * g.Wo, 1
+        a.batch, a.sYb, a.sXb, a.sOb = 1, 0, 0, 0
+        a.xf, a.alpha, a.prec = XF_NONE, 1.0, PRECISION
+        if _wgrad_wino(a, gv, bgrad_out, x.device):
+            return
     if kind == "c3up" and PHASE_UPCONV and xf == XF_NONE and x16 is None and _upconv_phase_wgrad(dy32, x, gv, bgrad_out, dy16):
         return
     npix = B * g.Ho * g.Wo
