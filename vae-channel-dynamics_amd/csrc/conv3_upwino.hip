@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void upwino_weights_kernel(const float* __rest
 }
 
 template <bool DG>
-__global__ __launch_bounds__(UNT, 2) void conv3_upwino_kernel(vae_igemm_args p, const float* __restrict__ U, int tiles_x, int tiles_y, int xcd_sp) {
+__global__ __launch_bounds__(UNT) __attribute__((amdgpu_waves_per_eu(5, 5))) void conv3_upwino_kernel(vae_igemm_args p, const float* __restrict__ U, int tiles_x, int tiles_y, int xcd_sp) {
   constexpr int WBN = 32 * UNB;           // output channels per workgroup
   constexpr int HW_ = DG ? 2 * UTW + 2 : UTW + 2;  // halo width in pixels
   constexpr int HP = DG ? UHD : UHF;      // halo pixels

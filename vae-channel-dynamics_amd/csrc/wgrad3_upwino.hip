@@ -13,26 +13,27 @@
 // Kernel: as wgrad3_wino.hip -- a unit = 8 low-resolution pixels of one row (a 2 x 16 strip of dY); per unit the 3 x 10-pixel halo
 // of x and the strip of dY go to LDS untransformed, transposed to [row][channel][x]; a wave builds its MFMA operands while
 // reading them; split-K slabs [split][9][Cin][Cout]; a reduction kernel sums the slabs in fixed order, applies A''^T . A'' and
-// writes OHWI -- with ONE POSITION PER WAVE: a workgroup is 9 waves (576 threads) = 32 ci x 64 co x 9 positions.  9 positions
-// do not divide over the 4 SIMDs of a CU; at 64 output channels a wave needs 32 accumulator registers (<= 96 VGPRs in all), so
-// TWO workgroups share a CU and their 18 waves fill the SIMDs 5 5 4 4.
+// writes OHWI.  Workgroup = 8 waves = 32 ci x 128 co x 9 positions: wave w owns position w (all four 32-channel blocks of co), and
+// the NINTH position is split by channel block over waves 0..3 -- one per SIMD (wave k of a workgroup runs on SIMD k % 4), so every
+// SIMD carries 36 MFMAs per step.  (A first version with one position per wave and 9 waves put three waves of every workgroup
+// on SIMD 0: 0.51 of the matrix peak.)  Two workgroups per CU (128 VGPRs).
 #include "common.h"
 #include <algorithm>
 #include <type_traits>
 
 namespace {
 
-constexpr int GCI = 32, GCO = 64, NPOS = 9, GNT = 64 * NPOS, GNB = GCO / 32;
+constexpr int GCI = 32, GCO = 128, NPOS = 9, GNT = 512, GNB = GCO / 32;
 constexpr int XSX = 12;                 // x pitch of a staged halo row (floats): 10 columns + padding (16-byte reads at 0 / 4 / 8)
 constexpr int XSY = 20;                 // x pitch of a staged dY row: 16 columns + padding
 constexpr int SXF = 3 * GCI * XSX;      // halo stage: [3 rows][32 ci][XSX]
-constexpr int SYF = 2 * GCO * XSY;      // dY stage:   [2 rows][64 co][XSY]
-constexpr int GSTAGE = SXF + SYF;       // 3712 floats (14848 B)
+constexpr int SYF = 2 * GCO * XSY;      // dY stage:   [2 rows][128 co][XSY]
+constexpr int GSTAGE = SXF + SYF;       // 6272 floats (25088 B)
 
-__global__ __launch_bounds__(GNT) __attribute__((amdgpu_waves_per_eu(5, 5))) void wgrad3_upwino_kernel(vae_wgrad_args p, int strips, int64_t nunits) {
+__global__ __launch_bounds__(GNT, 4) void wgrad3_upwino_kernel(vae_wgrad_args p, int strips, int64_t nunits) {
   __shared__ __attribute__((aligned(16))) float smem[2 * GSTAGE];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;  // wave = position (pr, pc) of the 3 x 3 transform domain
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;  // wave = position (pr, pc) 0..7; position 8: block `wave` on waves 0..3
   const int lr = lane & 31, lh = lane >> 5;
   const vae_conv_geom g = p.g;  // Hs x Ws: the low-resolution x; Ho x Wo = 2 Hs x 2 Ws: dY
   const int tilesN = p.N / GCI, ntile = tilesN * (p.M / GCO);
@@ -56,19 +57,20 @@ __global__ __launch_bounds__(GNT) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
   const int upi = g.Hs * strips;  // units per image
   const bool do_bias = (p.bias_partial != nullptr) && tn == 0;
 
-  // ---- staging roles.  dY strip (threads 0..511): column xx, channel quad yq, row ya.  x halo (threads 0..239): row xr,
+  // ---- staging roles.  dY strip (all 512 threads): column xx, channel quad yq, both rows.  x halo (threads 0..239): row xr,
   // column xc of the 3 x 10 halo, channel quad xq (fastest: 16-byte neighbours in memory) ----
-  const bool yrole = tid < 512;
-  const int xx = tid & 15, yq = (tid >> 4) & 15, ya = (tid >> 8) & 1;
+  const int xx = tid & 15, yq = tid >> 4;
   const bool xrole = tid < 240;
   const int xq = tid & 7, xc = (tid >> 3) % 10, xr = tid / 80;
   const auto rsX = VAE_BUF_RSRC(p.X, (size_t)g.B * g.Hs * g.Ws * g.Cs * 4u);
   const auto rsY = VAE_BUF_RSRC(p.dY, (size_t)g.B * g.Ho * g.Wo * p.ldy * 4u);
+  // ONE set of staging registers (the 128-VGPR budget of two workgroups per CU): unit k+1 is requested at the start of step k
+  // and stored at its end, behind the step's MFMAs
   struct Stg {
-    f32x4 rx, ry;
+    f32x4 rx, ry[2];
   };
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-  Stg s0{z4, z4}, s1 = s0;
+  Stg s0{z4, {z4, z4}};
   f32x4 bsum = z4;
   // the unit the next load_unit call requests (calls go through ubeg, ubeg+1, ...: counters instead of divisions per step)
   int ub = (int)(ubeg / upi), urow = (int)((ubeg - (int64_t)ub * upi) / strips), ustrip = (int)((ubeg - (int64_t)ub * upi) % strips);
@@ -87,7 +89,8 @@ __global__ __launch_bounds__(GNT) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     const bool xin = ok && xrole && ((unsigned)hy < (unsigned)g.Hs) && ((unsigned)hx < (unsigned)g.Ws);
     r.rx = VAE_BUF_LOAD4(rsX, xin ? (unsigned)((((b * g.Hs + hy) * g.Ws + hx) * g.Cs + n0 + 4 * xq) * 4) : BUF_OOB);
     const unsigned baseY = (unsigned)((b * g.Ho + 2 * i) * g.Wo + 2 * x0 + xx) * (unsigned)p.ldy * 4u + (unsigned)(m0 + 4 * yq) * 4u;
-    r.ry = VAE_BUF_LOAD4(rsY, (ok && yrole) ? baseY + ya * rowY : BUF_OOB);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) r.ry[a] = VAE_BUF_LOAD4(rsY, ok ? baseY + a * rowY : BUF_OOB);
   };
   auto store_unit = [&](float* st, const Stg& r) {
     float* sx = st;
@@ -96,110 +99,115 @@ __global__ __launch_bounds__(GNT) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 #pragma unroll
       for (int e = 0; e < 4; ++e) sx[(xr * GCI + 4 * xq + e) * XSX + xc] = r.rx[e];
     }
-    if (yrole) {  // (wave-uniform: waves 0..7)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) sy[(ya * GCO + 4 * yq + e) * XSY + xx] = r.ry[e];
-      if (do_bias) bsum += r.ry;
+    for (int a = 0; a < 2; ++a) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sy[(a * GCO + 4 * yq + e) * XSY + xx] = r.ry[a][e];
+      if (do_bias) bsum += r.ry[a];
     }
   };
 
-  f32x16 acc[GNB];
+  f32x16 acc[GNB], accx;  // accx: position 8, channel block `wave` (waves 0..3)
 #pragma unroll
   for (int nb = 0; nb < GNB; ++nb)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[nb][e] = 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) accx[e] = 0.f;
 
   load_unit(0, s0);
   store_unit(smem, s0);
-  load_unit(1, s1);
   __syncthreads();
 
-  // The loop body is instantiated per position: straight-line code, no per-step branches.
-  auto run = [&](auto PR, auto PC) {
+  // operand builders for position (pr, pc).  V fragment: lane (ci = lr, half lh) takes tiles 4 lh + e: halo columns 4 lh .. 4 lh + 5
+  // of the rows the position combines (rows 0, 1, 2 of the halo = x[i-1], x[i], x[i+1]: pr 0: r0 - r1, 1: r1, 2: r1 - r2).
+  // D fragment of channel block nb: tiles 4 lh + e = dY columns 8 lh + 2 e, + 1 (pr 0: dy row 0, 1: row 0 + row 1, 2: row 1).
+  auto build_a = [&](auto PR, auto PC, const float* cx, f32x4& a4) {
     constexpr int pr = decltype(PR)::value, pc = decltype(PC)::value;
-    // V row combination (rows 0, 1, 2 of the halo = x[i-1], x[i], x[i+1]): pr 0: r0 - r1, 1: r1, 2: r1 - r2
     constexpr int vr1 = pr == 0 ? 0 : 1, vr2 = pr == 0 ? 1 : 2;
     const int voff1 = (vr1 * GCI + lr) * XSX + 4 * lh, voff2 = (vr2 * GCI + lr) * XSX + 4 * lh;
-    // D row combination: pr 0: dy row 0, 1: row 0 + row 1, 2: row 1
+    float rc[8];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const f32x4 u1 = *reinterpret_cast<const f32x4*>(&cx[voff1 + 4 * c]);
+      if (pr == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rc[4 * c + e] = u1[e];
+      } else {
+        const f32x4 u2 = *reinterpret_cast<const f32x4*>(&cx[voff2 + 4 * c]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rc[4 * c + e] = u1[e] - u2[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a4[e] = pc == 0 ? rc[e] - rc[e + 1] : (pc == 1 ? rc[e + 1] : rc[e + 1] - rc[e + 2]);
+  };
+  auto build_b = [&](auto PR, auto PC, const float* cy, int nb, f32x4& b4) {
+    constexpr int pr = decltype(PR)::value, pc = decltype(PC)::value;
     constexpr int dr1 = pr == 2 ? 1 : 0;
-    auto step = [&](int k, const Stg& cur, Stg& nxt) {  // cur: unit k+1 (requested during step k-1); nxt receives unit k+2
-      load_unit(k + 2, nxt);
+    const int doff = (dr1 * GCO + nb * 32 + lr) * XSY + 8 * lh;
+    float rc[8];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const f32x4 d0 = *reinterpret_cast<const f32x4*>(&cy[doff + 4 * c]);
+      if (pr == 1) {
+        const f32x4 d1 = *reinterpret_cast<const f32x4*>(&cy[doff + GCO * XSY + 4 * c]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rc[4 * c + e] = d0[e] + d1[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rc[4 * c + e] = d0[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) b4[e] = pc == 0 ? rc[2 * e] : (pc == 1 ? rc[2 * e] + rc[2 * e + 1] : rc[2 * e + 1]);
+  };
+  using I2 = std::integral_constant<int, 2>;
+
+  // The loop body is instantiated per position: straight-line code, no per-step branches.
+  auto run = [&](auto PR, auto PC, auto EXTRA) {
+    constexpr bool extra = decltype(EXTRA)::value;  // this wave also owns block `wave` of position 8 = (2, 2)
+    for (int k = 0; k < nu; ++k) {
+      load_unit(k + 1, s0);  // (s0's previous contents were stored at the end of step k-1)
       const float* cx = smem + (k & 1) * GSTAGE;
       const float* cy = cx + SXF;
       float* nst = smem + ((k + 1) & 1) * GSTAGE;
-      // V fragment: lane (ci = lr, half lh) takes tiles 4 lh + e: halo columns 4 lh .. 4 lh + 5
-      f32x4 a4;
-      {
-        float rc[8];
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const f32x4 u1 = *reinterpret_cast<const f32x4*>(&cx[voff1 + 4 * c]);
-          if (pr == 1) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) rc[4 * c + e] = u1[e];
-          } else {
-            const f32x4 u2 = *reinterpret_cast<const f32x4*>(&cx[voff2 + 4 * c]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) rc[4 * c + e] = u1[e] - u2[e];
-          }
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) a4[e] = pc == 0 ? rc[e] - rc[e + 1] : (pc == 1 ? rc[e + 1] : rc[e + 1] - rc[e + 2]);
-      }
-      // D fragments of channel block nb: tiles 4 lh + e = dY columns 8 lh + 2 e, + 1
-      auto build_b = [&](int nb, f32x4& b4) {
-        const int doff = (dr1 * GCO + nb * 32 + lr) * XSY + 8 * lh;
-        float rc[8];
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const f32x4 d0 = *reinterpret_cast<const f32x4*>(&cy[doff + 4 * c]);
-          if (pr == 1) {
-            const f32x4 d1 = *reinterpret_cast<const f32x4*>(&cy[doff + GCO * XSY + 4 * c]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) rc[4 * c + e] = d0[e] + d1[e];
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) rc[4 * c + e] = d0[e];
-          }
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) b4[e] = pc == 0 ? rc[2 * e] : (pc == 1 ? rc[2 * e] + rc[2 * e + 1] : rc[2 * e + 1]);
-      };
-      f32x4 bb[2];
-      build_b(0, bb[0]);
-      if (wave < 4) store_unit(nst, cur);  // the waves of a SIMD store at opposite ends of the step
+      f32x4 a4, bb[2];
+      build_a(PR, PC, cx, a4);
+      build_b(PR, PC, cy, 0, bb[0]);
 #pragma unroll
       for (int nb = 0; nb < GNB; ++nb) {
         __builtin_amdgcn_sched_barrier(0);
-        if (nb + 1 < GNB) build_b(nb + 1, bb[(nb + 1) & 1]);  // the next block's operands, while this block's MFMAs issue
+        if (nb + 1 < GNB) build_b(PR, PC, cy, nb + 1, bb[(nb + 1) & 1]);  // the next block's operands, while this block's MFMAs issue
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], bb[nb & 1][e], acc[nb], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (wave >= 4) store_unit(nst, cur);
+      if (extra) {
+        f32x4 ax, bx;
+        build_a(I2{}, I2{}, cx, ax);
+        build_b(I2{}, I2{}, cy, wave, bx);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) accx = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[e], bx[e], accx, 0, 0, 0);
+      }
+      store_unit(nst, s0);
       __syncthreads();
-    };
-    int k = 0;
-    for (; k + 1 < nu; k += 2) {
-      step(k, s1, s0);
-      step(k + 1, s0, s1);
     }
-    if (k < nu) step(k, s1, s0);
   };
   {
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>;
-    switch (wave) {  // (wave-uniform: pr = wave / 3, pc = wave % 3)
-      case 0: run(I0{}, I0{}); break;
-      case 1: run(I0{}, I1{}); break;
-      case 2: run(I0{}, I2{}); break;
-      case 3: run(I1{}, I0{}); break;
-      case 4: run(I1{}, I1{}); break;
-      case 5: run(I1{}, I2{}); break;
-      case 6: run(I2{}, I0{}); break;
-      case 7: run(I2{}, I1{}); break;
-      default: run(I2{}, I2{}); break;
+    using T = std::true_type;
+    using F_ = std::false_type;
+    switch (wave) {  // (wave-uniform: pr = wave / 3, pc = wave % 3; waves 0..3 carry the ninth position's blocks)
+      case 0: run(I0{}, I0{}, T{}); break;
+      case 1: run(I0{}, I1{}, T{}); break;
+      case 2: run(I0{}, I2{}, T{}); break;
+      case 3: run(I1{}, I0{}, T{}); break;
+      case 4: run(I1{}, I1{}, F_{}); break;
+      case 5: run(I1{}, I2{}, F_{}); break;
+      case 6: run(I2{}, I0{}, F_{}); break;
+      default: run(I2{}, I1{}, F_{}); break;
     }
   }
 
@@ -212,24 +220,20 @@ __global__ __launch_bounds__(GNT) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
       const int ci = n0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
       O[((int64_t)wave * p.N + ci) * p.M + m0 + nb * 32 + lr] = acc[nb][e];
     }
-  if (do_bias) {  // workgroup-uniform: thread sums of its (row, channel quad) over the 16 columns of the strip, then row 0 + row 1
-    float* red = smem;  // [64] (the main loop's last barrier has passed)
-    float sq[4];
+  if (wave < 4) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int ci = n0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      O[((int64_t)8 * p.N + ci) * p.M + m0 + wave * 32 + lr] = accx[e];
+    }
+  }
+  if (do_bias) {  // workgroup-uniform: thread sums of its channel quad -> over the 16 columns of the strip
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      float s = bsum[e];
+      float sv = bsum[e];
 #pragma unroll
-      for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 64);
-      sq[e] = s;
-    }
-    if (yrole && ya == 1 && xx == 0) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) red[4 * yq + e] = sq[e];
-    }
-    __syncthreads();
-    if (yrole && ya == 0 && xx == 0) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) p.bias_partial[(int64_t)split * p.M + m0 + 4 * yq + e] = sq[e] + red[4 * yq + e];
+      for (int o = 1; o < 16; o <<= 1) sv += __shfl_xor(sv, o, 64);
+      if (xx == 0) p.bias_partial[(int64_t)split * p.M + m0 + 4 * yq + e] = sv;
     }
   }
 }
@@ -290,7 +294,7 @@ __global__ __launch_bounds__(256) void upwino_wgrad_reduce_kernel(const float* _
 }  // namespace
 
 // conv3x3(nearest_upsample_2x(x)) in fp32: geometry mode UP2X (source = the low-resolution x, row grid = dY at twice the size),
-// 8 | low-resolution width, 32 | Cin, 64 | Cout
+// 8 | low-resolution width, 32 | Cin, 128 | Cout
 bool wgrad3_upwino_eligible(const vae_wgrad_args& a) {
   const vae_conv_geom& g = a.g;
   if (a.prec != VAE_PREC_F32 || a.X16 != nullptr || a.dY16 != nullptr || a.dY == nullptr || a.batch != 1 || a.alpha != 1.0f) return false;
