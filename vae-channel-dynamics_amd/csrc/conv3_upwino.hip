@@ -18,10 +18,11 @@
 //
 // Kernel: as conv3_wino.hip (transformed weights U = G' g G'^T rebuilt from the live weights per launch, layout [K/8][9][N][8];
 // chunk of 8 channels per step; the chunk's halo staged once, the V image [9][32 tiles][8] double buffered in LDS; U fragments
-// from L2 straight into registers one step ahead; accumulators through LDS in the epilogue), with ONE POSITION PER WAVE:
-// a workgroup is 9 waves (576 threads) = 32 low-resolution pixels (4 x 8) x 64 channels.  9 positions do not divide over the
-// 4 SIMDs of a CU, but a wave needs only 32 accumulator registers, so three or more workgroups share a CU and the waves of
-// consecutive workgroups fill the SIMDs evenly (two workgroups: 5 5 4 4 waves).
+// from L2 straight into registers one step ahead; accumulators through LDS in the epilogue).  Workgroup = 8 waves = 32
+// low-resolution pixels (4 x 8) x 64 channels: wave w owns position w (both 32-channel blocks) and the NINTH position is split
+// by channel block over two waves on different SIMDs (waves 0, 1 in even workgroups, 2, 3 in odd ones: wave k of a workgroup runs on
+// SIMD k % 4), so a workgroup loads the SIMDs 20 20 16 16 MFMAs per step and two co-resident workgroups 36 each.  (A first
+// version with one position per wave and 9 waves put three waves of every workgroup on SIMD 0: 0.46 of the matrix peak.)
 #include "common.h"
 #include <algorithm>
 
@@ -31,7 +32,7 @@ constexpr int UTH = 4, UTW = 8;            // low-resolution pixels (= Winograd 
 constexpr int UTL = UTH * UTW;             // 32
 constexpr int UBK = 8;                     // channels per step
 constexpr int NPOS = 9;
-constexpr int UNT = 64 * NPOS;             // 576 threads
+constexpr int UNT = 512;                   // 8 waves
 constexpr int UNB = 2;                     // 32-channel blocks per workgroup
 constexpr int USV = NPOS * UTL * UBK;      // floats per V buffer (9216 B)
 constexpr int UHF = (UTH + 2) * (UTW + 2); // forward halo pixels (6 x 10)
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(256) void upwino_weights_kernel(const float* __rest
 }
 
 template <bool DG>
-__global__ __launch_bounds__(UNT) __attribute__((amdgpu_waves_per_eu(5, 5))) void conv3_upwino_kernel(vae_igemm_args p, const float* __restrict__ U, int tiles_x, int tiles_y, int xcd_sp) {
+__global__ __launch_bounds__(UNT, 4) void conv3_upwino_kernel(vae_igemm_args p, const float* __restrict__ U, int tiles_x, int tiles_y, int xcd_sp) {
   constexpr int WBN = 32 * UNB;           // output channels per workgroup
   constexpr int HW_ = DG ? 2 * UTW + 2 : UTW + 2;  // halo width in pixels
   constexpr int HP = DG ? UHD : UHF;      // halo pixels
@@ -81,7 +82,11 @@ __global__ __launch_bounds__(UNT) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
   float* const sV = wsm;            // [2][USV]
   float* const sH = wsm + 2 * USV;  // [2][USH]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;  // wave = position of the 3 x 3 transform domain
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;  // wave = position 0..7 of the 3 x 3 transform domain
+  // position 8: channel block 0 on wave xw0, block 1 on wave xw0 + 1
+  const int xw0 = (blockIdx.x & 1) * 2;
+  const bool extra = wave == xw0 || wave == xw0 + 1;  // uniform per wave
+  const int xnb = wave - xw0;
   const int lr = lane & 31, lh = lane >> 5;
   const vae_conv_geom g = p.g;
   const int tilesN = (p.N + WBN - 1) / WBN;
@@ -167,25 +172,27 @@ __global__ __launch_bounds__(UNT) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 #pragma unroll
   for (int q = 0; q < UNB; ++q) bvo[q] = (n0 + q * 32 + lr < p.N) ? (unsigned)(((n0 + q * 32 + lr) * 8 + lh * 4) * 4) : BUF_OOB;
   const unsigned bpos = (unsigned)p.N * 32u;  // bytes per position of the U image
-  auto load_b = [&](int step, f32x4 (&bq)[UNB]) {
+  const unsigned bvx = extra ? bvo[xnb & 1] : BUF_OOB;  // the ninth position's block (waves without one request nothing)
+  auto load_b = [&](int step, f32x4 (&bq)[UNB + 1]) {
     if (step >= nsteps) return;  // (uniform; the registers are not used again)
     const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(step * NPOS + wave) * bpos);
+    const unsigned sx = __builtin_amdgcn_readfirstlane((unsigned)(step * NPOS + 8) * bpos);
 #pragma unroll
     for (int i = 0; i < UNB; ++i) bq[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsU, bvo[i], so, 0));
+    bq[UNB] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsU, bvx, sx, 0));
   };
 
-  f32x16 acc[UNB];
+  f32x16 acc[UNB], accx;
 #pragma unroll
   for (int nb = 0; nb < UNB; ++nb)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[nb][e] = 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) accx[e] = 0.f;
 
-  // prologue: halo(0), halo(1) in LDS, V(0) from halo(0); halo(2) and the U fragments of steps 0 and 1 in registers.  THREE
-  // register sets carry the U stream: a step here is 8 MFMAs per wave (~0.5 us for the workgroup), shorter than an L2 round trip
-  // under load, so the fragments of step s+2 are requested during step s (one step of lead left the matrix pipe at 0.46)
-  f32x4 bq0[UNB], bq1[UNB], bq2[UNB];
+  // prologue: halo(0), halo(1) in LDS, V(0) from halo(0); halo(2) and the U fragments of step 0 in registers
+  f32x4 bq0[UNB + 1], bq1[UNB + 1];
   load_b(0, bq0);
-  load_b(1, bq1);
   {
     f32x4 h0, h1;
     load_halo_into(0, h0);
@@ -197,39 +204,46 @@ __global__ __launch_bounds__(UNT) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
   __syncthreads();
   write_v(sH, sV);
   __syncthreads();
-  auto multiply = [&](const f32x4& a4, const f32x4 (&bq)[UNB]) {
+  auto multiply = [&](const float* cV, const f32x4 (&bq)[UNB + 1]) {
+    const f32x4 a4 = *reinterpret_cast<const f32x4*>(&cV[(wave * UTL + lr) * UBK + 4 * lh]);
+    f32x4 ax = a4;
+    if (extra) ax = *reinterpret_cast<const f32x4*>(&cV[(8 * UTL + lr) * UBK + 4 * lh]);
 #pragma unroll
     for (int nb = 0; nb < UNB; ++nb)
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], bq[nb][e], acc[nb], 0, 0, 0);
+    if (extra) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) accx = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[e], bq[UNB][e], accx, 0, 0, 0);
+    }
   };
   auto stage_next = [&](int s, int par) {
     if (s + 1 < nsteps) write_v(sH + (par ^ 1) * USH, sV + (par ^ 1) * USV);  // V(s+1): nobody reads that buffer now
     store_halo_from(sH + par * USH, rh);                                       // halo(s+2)
     load_halo_into(s + 3, rh);
   };
-  auto step = [&](int s, int par, const f32x4 (&cur)[UNB], f32x4 (&nxt)[UNB]) {  // nxt: the set step s-1 used, receives step s+2
+  auto step = [&](int s, int par, const f32x4 (&cur)[UNB + 1], f32x4 (&nxt)[UNB + 1]) {
     const float* cV = sV + par * USV;
-    load_b(s + 2, nxt);
+    load_b(s + 1, nxt);
     __builtin_amdgcn_sched_barrier(0);
     if (wave < 4) {  // uniform per wave: the waves that own the V transform stage first, the others multiply first
       stage_next(s, par);
-      const f32x4 a4 = *reinterpret_cast<const f32x4*>(&cV[(wave * UTL + lr) * UBK + 4 * lh]);
       __builtin_amdgcn_sched_barrier(0);
-      multiply(a4, cur);
+      multiply(cV, cur);
     } else {
-      const f32x4 a4 = *reinterpret_cast<const f32x4*>(&cV[(wave * UTL + lr) * UBK + 4 * lh]);
-      multiply(a4, cur);
+      multiply(cV, cur);
       __builtin_amdgcn_sched_barrier(0);
       stage_next(s, par);
     }
     __syncthreads();
   };
-  for (int s = 0; s < nsteps; ++s) {  // step s multiplies set s % 3 and refills set (s + 2) % 3
-    const int par = s & 1, r3 = s % 3;
-    if (r3 == 0) step(s, par, bq0, bq2);
-    else if (r3 == 1) step(s, par, bq1, bq0);
-    else step(s, par, bq2, bq1);
+  {
+    int s = 0;
+    for (; s + 1 < nsteps; s += 2) {
+      step(s, 0, bq0, bq1);
+      step(s + 1, 1, bq1, bq0);
+    }
+    if (s < nsteps) step(s, 0, bq0, bq1);
   }
 
   // ---- epilogue: per 32-channel block, M through LDS, then the output transform ----
@@ -244,8 +258,15 @@ __global__ __launch_bounds__(UNT) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
       const int tile = (e & 3) + 8 * (e >> 2) + 4 * lh;
       sM[(wave * UTL + tile) * UMLD + lr] = acc[nb][e];
     }
+    if (wave == xw0 + nb) {  // the ninth position's block nb
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int tile = (e & 3) + 8 * (e >> 2) + 4 * lh;
+        sM[(8 * UTL + tile) * UMLD + lr] = accx[e];
+      }
+    }
     __syncthreads();
-    if (tid < 512) {
+    {
 #pragma unroll
       for (int rnd = 0; rnd < 2; ++rnd) {
         const int co = tid & 31, tile = (tid >> 5) + 16 * rnd;
