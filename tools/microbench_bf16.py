@@ -41,16 +41,18 @@ def main():
         ops.WEIGHTS16 = (wbuf.data_ptr(), wbuf.numel() * 4, img.data_ptr())
         gw = torch.empty_like(wbuf).permute(0, 3, 1, 2)
         gb = torch.empty(Co, device="cuda")
-        st = ops.gn_stats(x, torch.ones(Ci, device="cuda"), torch.zeros(Ci, device="cuda"))
-        a16 = ops.gn_apply_bf16(x, st, ops.XF_AFFINE_SILU)
+        x16 = x.bfloat16()  # round 3: activations and gradients are stored as bf16 (ops.ACT_BF16)
+        st = ops.gn_stats(x16, torch.ones(Ci, device="cuda"), torch.zeros(Ci, device="cuda"))
+        a16 = ops.gn_apply_bf16(x16, st, ops.XF_AFFINE_SILU)
         dy16 = dy.bfloat16()
+        res16 = res.bfloat16()
         fl = 2.0 * B * H * H * Ci * Co * 9
         runs = {
-            "fwd_img": lambda: ops.conv_fwd(x, w, None, "c3", xf=ops.XF_AFFINE_SILU, stats=st, a16=a16),
-            "fwd_img_full": lambda: ops.conv_fwd(x, w, bias, "c3", xf=ops.XF_AFFINE_SILU, stats=st, a16=a16, res=res, gstat_groups=32),
+            "fwd_img": lambda: ops.conv_fwd(x16, w, None, "c3", xf=ops.XF_AFFINE_SILU, stats=st, a16=a16),
+            "fwd_img_bias_gstat": lambda: ops.conv_fwd(x16, w, bias, "c3", xf=ops.XF_AFFINE_SILU, stats=st, a16=a16, gstat_groups=32),
+            "fwd_img_full": lambda: ops.conv_fwd(x16, w, bias, "c3", xf=ops.XF_AFFINE_SILU, stats=st, a16=a16, res=res16, gstat_groups=32),
             "dgrad_img": lambda: ops.conv_dgrad(dy16, w, "c3", (H, H)),
-            "dgrad_img_o16": lambda: ops.conv_dgrad(dy16, w, "c3", (H, H), out_bf16=True),
-            "wgrad_img": lambda: ops.conv_wgrad(dy16, x, "c3", gw, gb, x16=a16),
+            "wgrad_img": lambda: ops.conv_wgrad(dy16, x16, "c3", gw, gb, x16=a16),
         }
         for variant in ("wide", "tile128"):
             ops.lib.call("vae_set_option", b"no_wide", 1 if variant == "tile128" else 0)
@@ -58,7 +60,7 @@ def main():
                 if variant == "tile128" and k.startswith("wgrad"):
                     continue
                 ms = timeit(fn)
-                print(f"{nm:6s} {variant:8s} {k:14s} {ms:8.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s", flush=True)
+                print(f"{nm:6s} {variant:8s} {k:20s} {ms:8.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s", flush=True)
         ops.lib.call("vae_set_option", b"no_wide", 0)
 
 
