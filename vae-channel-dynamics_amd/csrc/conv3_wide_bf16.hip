@@ -277,7 +277,15 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
 
   constexpr std::integral_constant<int, 0> p0{};
   constexpr std::integral_constant<int, 1> p1{};
+#ifdef VAE_WIDE_TIMING  // debug build (tools/wide_timing.py): shader-clock stamps of workgroup 0's tiles into p.track (as uint64)
+  unsigned long long* tstamp = reinterpret_cast<unsigned long long*>(p.track);
+  int titer = 0;
+#define TSTAMP(k) do { if (tstamp && blockIdx.x == 0 && tid == 0 && titer < 64) tstamp[titer * 4 + (k)] = clock64(); } while (0)
+#else
+#define TSTAMP(k) do { } while (0)
+#endif
   while (true) {
+    TSTAMP(0);
     if constexpr (KS == 3) {  // 3 stages per chunk: the stage parity repeats every 2 chunks (the launcher checks nch % 2 == 0)
       for (int c = 0; c < nch; c += 2) {
         stage(kw0_c, p0);
@@ -298,6 +306,7 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
     }
 
     // ---------------- epilogue ----------------
+    TSTAMP(1);
     float* scratch = reinterpret_cast<float*>(sHalo + (hpar ^ 1) * SH);  // the halo buffer of the chunk just finished
     const size_t obytes = (size_t)(g.Ho * cs) * (g.Wo * cs) * p.ldc * 4u;
     const auto rsC = VAE_BUF_RSRC(p.C + (int64_t)cur.b * (g.Ho * cs) * (g.Wo * cs) * p.ldc, obytes);
@@ -401,6 +410,7 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
         }
       }
     }
+    TSTAMP(2);
     if (p.gstat) {  // uniform: centred moments (mean, M2) of this tile's outputs per group (layout of vae_gn_stats_partial, one chunk per tile)
       const int cpg = p.N / p.gstat_groups, gpt = BN / cpg;  // channels per group (4, 8 or 16), groups per 128-channel tile
       float* red2 = scratch;                                  // [8 rows][gpt][2]
@@ -429,6 +439,10 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
       __syncthreads();
     }
 
+    TSTAMP(3);
+#ifdef VAE_WIDE_TIMING
+    ++titer;
+#endif
     t += G;
     if (t >= ntiles) break;
     cur = decode(t);
@@ -460,7 +474,9 @@ bool conv3_wide_bf16_eligible(const vae_igemm_args& a) {
   const vae_conv_geom& g = a.g;
   if (a.prec != VAE_PREC_BF16 || a.A16 == nullptr || a.Wh == nullptr || a.xf != VAE_XF_NONE) return false;
   if (a.batch != 1 || g.taps != 9 || g.stride != 1 || g.pad_t != 1 || g.pad_l != 1 || a.alpha != 1.0f) return false;
+#ifndef VAE_WIDE_TIMING
   if (a.track != nullptr) return false;
+#endif
   // a residual input on a 128-channel contraction: the tile's main loop (12 stages, ~9 us) is shorter than what one CU needs
   // to pull the 128 KB residual tile and push the 128 KB output (~10 us at a CU's ~26 GB/s), and with one workgroup per CU
   // nothing overlaps the two -- the 128-pixel kernel's second workgroup does (measured 0.505 vs 0.588 ms at 128->128 @256^2)

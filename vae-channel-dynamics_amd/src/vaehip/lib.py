@@ -5,7 +5,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "csrc", "libvaehip.so"))
+# VAEHIP_LIB: another build of the library (development: instrumented builds such as csrc/libvaehip_timing.so)
+LIB_PATH = os.environ.get("VAEHIP_LIB") or os.path.normpath(os.path.join(_HERE, "..", "..", "csrc", "libvaehip.so"))
 
 
 class VaeHipError(RuntimeError):
