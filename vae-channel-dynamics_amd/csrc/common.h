@@ -96,16 +96,44 @@ __device__ __forceinline__ MeanM2 mm2_from_shifted(float pv, float s1, float s2,
   const float dm = s1 / n;
   return MeanM2{pv + dm, fmaxf(s2 - s1 * dm, 0.f)};
 }
-// merge over the `cpg` adjacent lanes of a group and the two lane halves (each lane starts with n0 elements)
+// Cross-lane moves that stay in the VALU.  A __shfl_xor compiles to ds_bpermute_b32 -- the LDS pipe plus an s_waitcnt per use;
+// in the bf16 epilogues (64 swaps per wave tile + the statistics merges) that was 8 of 12 us per tile (tools/wide_timing.py).
+// lane_xor1: the value of lane i ^ 1 (DPP quad_perm [1,0,3,2]); lane_plus<O>: of lane i + O inside its row of 16 lanes (DPP
+// row_shl; lanes past the row read 0); lane_xor32: of lane i ^ 32 (v_permlane32_swap, gfx950).
+__device__ __forceinline__ float lane_xor1(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+template <int O>
+__device__ __forceinline__ float lane_plus(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x100 + O, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float lane_xor32(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);  // r[0]: lanes 32.. got lanes 0..31; r[1]: lanes 0..31 got lanes 32..
+  return __builtin_bit_cast(float, (threadIdx.x & 32) ? r[0] : r[1]);
+}
+// merge over the `cpg` adjacent lanes of a group (cpg = 1, 2, 4, 8 or 16: groups are aligned inside a 16-lane row) and the two
+// lane halves (each lane starts with n0 elements).  Lane i merges lane i + o for o = 1, 2, .. cpg/2: afterwards the FIRST lane
+// of a group holds the group's moments (the other lanes partial ones); callers read lanes with lh == 0 && lr % cpg == 0 only.
 __device__ __forceinline__ MeanM2 mm2_wave_group(MeanM2 a, int cpg, float n0) {
   float n = n0;
-  for (int o = 1; o < cpg; o <<= 1) {
-    MeanM2 b{__shfl_xor(a.m, o, 64), __shfl_xor(a.M2, o, 64)};
-    a = mm2_merge_equal(a, b, n);
+  if (cpg > 1) {  // (uniform)
+    a = mm2_merge_equal(a, MeanM2{lane_plus<1>(a.m), lane_plus<1>(a.M2)}, n);
     n *= 2.f;
   }
-  MeanM2 b{__shfl_xor(a.m, 32, 64), __shfl_xor(a.M2, 32, 64)};
-  return mm2_merge_equal(a, b, n);
+  if (cpg > 2) {
+    a = mm2_merge_equal(a, MeanM2{lane_plus<2>(a.m), lane_plus<2>(a.M2)}, n);
+    n *= 2.f;
+  }
+  if (cpg > 4) {
+    a = mm2_merge_equal(a, MeanM2{lane_plus<4>(a.m), lane_plus<4>(a.M2)}, n);
+    n *= 2.f;
+  }
+  if (cpg > 8) {
+    a = mm2_merge_equal(a, MeanM2{lane_plus<8>(a.m), lane_plus<8>(a.M2)}, n);
+    n *= 2.f;
+  }
+  return mm2_merge_equal(a, MeanM2{lane_xor32(a.m), lane_xor32(a.M2)}, n);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -350,7 +350,7 @@ __global__ __launch_bounds__(NT, 2) void conv3_tile_bf16_kernel(vae_igemm_args p
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const float a0 = p.alpha * acc[mi][ni][2 * j], a1 = p.alpha * acc[mi][ni][2 * j + 1];
-            const float recv = __shfl_xor(odd ? a0 : a1, 1, 64);
+            const float recv = lane_xor1(odd ? a0 : a1);
             typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
             bf16x2_t h;
             h[0] = (__bf16)((odd ? recv : a0) + b0 + __builtin_bit_cast(float, rr[j] << 16));
@@ -392,32 +392,22 @@ __global__ __launch_bounds__(NT, 2) void conv3_tile_bf16_kernel(vae_igemm_args p
         }
       }
     }
-    if (p.gstat) {  // uniform: GroupNorm partial sums of this tile's outputs (layout of vae_gn_stats_partial)
-      const int cpg = p.N / p.gstat_groups, gpt = BN / cpg;  // channels per group (4, 8 or 16), groups per 128-channel tile
-      float* red2 = reinterpret_cast<float*>(smem) + 4 * BN;  // [4 rows][gpt][2] behind the tracker scratch, in the halo stage
+    if (p.gstat) {  // uniform: GroupNorm moments of this tile's outputs, layout of vae_gn_stats_partial with one chunk per ROW of the
+      // tile (32 pixels): written straight from registers, no LDS round trip / barrier (see conv3_wide_bf16.hip)
+      const int cpg = p.N / p.gstat_groups;  // channels per group (4, 8 or 16)
+      const int tile_in_img = cur.lin - cur.b * (tiles_x * tiles_y);
+      float* gbase = p.gstat + ((int64_t)cur.b * (tiles_x * tiles_y) + tile_in_img) * TH * p.gstat_groups * 2;
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
           const MeanM2 a = mm2_wave_group(mm2_from_shifted(gpv[mi][ni], gs1[mi][ni], gs2[mi][ni], 16.f), cpg, 16.f);
           if (lh == 0 && (lr & (cpg - 1)) == 0) {
-            const int gl = (wn * 64 + ni * 32 + lr) / cpg;
-            red2[((2 * wm + mi) * gpt + gl) * 2] = a.m;
-            red2[((2 * wm + mi) * gpt + gl) * 2 + 1] = a.M2;
+            float* o = gbase + ((2 * wm + mi) * p.gstat_groups + (cur.n0 + wn * 64 + ni * 32 + lr) / cpg) * 2;
+            o[0] = a.m;
+            o[1] = a.M2;
           }
         }
-      __syncthreads();
-      if (tid < gpt) {  // the 4 rows of the tile, fixed order; each holds 32 pixels x cpg channels
-        const float nrow = 32.f * (float)cpg;
-        MeanM2 a{red2[tid * 2], red2[tid * 2 + 1]};
-#pragma unroll
-        for (int rr = 1; rr < 4; ++rr) a = mm2_merge(a, nrow * (float)rr, MeanM2{red2[(rr * gpt + tid) * 2], red2[(rr * gpt + tid) * 2 + 1]}, nrow);
-        const int tile_in_img = cur.lin - cur.b * (tiles_x * tiles_y);
-        float* o = p.gstat + (((int64_t)cur.b * (tiles_x * tiles_y) + tile_in_img) * p.gstat_groups + cur.n0 / cpg + tid) * 2;
-        o[0] = a.m;
-        o[1] = a.M2;
-      }
-      __syncthreads();
     }
     if (p.track) {  // uniform; the last loop barrier separated the halo reads from this reuse of its space
       float* red = reinterpret_cast<float*>(smem);  // [4 rows][BN] fp32 = 2 KB of the 16 KB halo stage
@@ -455,6 +445,15 @@ void launch_xf(const vae_igemm_args& a, dim3 grid, int tx, int ty, int nt, hipSt
 }
 
 }  // namespace
+
+// chunks per image of the statistics epilogue: one per row of a 4 x 32-pixel tile (0 = not available for these arguments)
+int conv3_tile_bf16_gstat_chunks(const vae_igemm_args& a) {
+  const vae_conv_geom& g = a.g;
+  if (a.gstat_groups <= 0 || a.N % BN != 0 || a.N % a.gstat_groups != 0 || g.mode == VAE_MODE_DGRAD || a.c_step > 1) return 0;
+  const int cpg = a.N / a.gstat_groups;
+  if (cpg != 4 && cpg != 8 && cpg != 16) return 0;
+  return (g.Wo / TW) * g.Ho;
+}
 
 // the kernel reads the weights from their bf16 image in 16-byte (8-element) pieces: they must be aligned and never
 // straddle a row end

@@ -178,6 +178,16 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
   if (t >= ntiles) return;  // uniform
   Tile cur = decode(t);
   int hpar = 0;  // halo buffer of the chunk being multiplied
+#ifdef VAE_WIDE_SKEW
+  // Persistent workgroups with equal tiles run in lockstep: all 256 CUs store their output tiles at the same moment (a burst of
+  // 16+ MB while HBM idles during the main loops).  Odd workgroups start half a tile late, so only half of the CUs are in
+  // their epilogue at any time.  Only where a workgroup runs many tiles (the idle half tile at the start / end is then cheap).
+  if ((blockIdx.x & 1) && ntiles >= 8 * G) {
+    const long long wait = (long long)nch * KS * 1200 + 9000;  // ~ half a tile in shader-clock ticks
+    const long long t0 = clock64();
+    while (clock64() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+  }
+#endif
 
   // prologue: the first two stages and the first halo into LDS, the third stage into registers
   u16* ringB[3] = {sW, sW + SB, sW + 2 * SB};  // [0] the stage being multiplied, [1] the next one, [2] the one being written
@@ -307,7 +317,6 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
 
     // ---------------- epilogue ----------------
     TSTAMP(1);
-    float* scratch = reinterpret_cast<float*>(sHalo + (hpar ^ 1) * SH);  // the halo buffer of the chunk just finished
     const size_t obytes = (size_t)(g.Ho * cs) * (g.Wo * cs) * p.ldc * 4u;
     const auto rsC = VAE_BUF_RSRC(p.C + (int64_t)cur.b * (g.Ho * cs) * (g.Wo * cs) * p.ldc, obytes);
     const auto rsR = VAE_BUF_RSRC((p.res ? p.res : p.C) + (int64_t)cur.b * (g.Ho * cs) * (g.Wo * cs) * p.ldc, obytes);
@@ -350,7 +359,7 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const float a0 = acc[r][ni][2 * j], a1 = acc[r][ni][2 * j + 1];
-            const float recv = __shfl_xor(odd ? a0 : a1, 1, 64);
+            const float recv = lane_xor1(odd ? a0 : a1);
             typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
             bf16x2_t h;
             h[0] = (__bf16)((odd ? recv : a0) + b0 + __builtin_bit_cast(float, rr[q][j] << 16));
@@ -411,34 +420,24 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
       }
     }
     TSTAMP(2);
-    if (p.gstat) {  // uniform: centred moments (mean, M2) of this tile's outputs per group (layout of vae_gn_stats_partial, one chunk per tile)
-      const int cpg = p.N / p.gstat_groups, gpt = BN / cpg;  // channels per group (4, 8 or 16), groups per 128-channel tile
-      float* red2 = scratch;                                  // [8 rows][gpt][2]
+    if (p.gstat) {  // uniform: centred moments (mean, M2) of this tile's outputs per group, layout of vae_gn_stats_partial with one
+      // chunk per ROW of the tile (32 pixels): a wave writes the moments of its own rows straight from registers -- no LDS round
+      // trip, no workgroup barrier (the tile-level merge of round 2 cost 3.5 us per tile, tools/wide_timing.py)
+      const int cpg = p.N / p.gstat_groups;  // channels per group (4, 8 or 16)
+      const int tile_in_img = cur.lin - cur.b * (tiles_x * tiles_y);
+      float* gbase = p.gstat + ((int64_t)cur.b * (tiles_x * tiles_y) + tile_in_img) * TH * p.gstat_groups * 2;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
           const MeanM2 a = mm2_wave_group(mm2_from_shifted(gpv[r][ni], gs1[r][ni], gs2[r][ni], 16.f), cpg, 16.f);
           if (lh == 0 && (lr & (cpg - 1)) == 0) {
-            const int gl = (wn * 64 + ni * 32 + lr) / cpg;
-            red2[((4 * wm + r) * gpt + gl) * 2] = a.m;
-            red2[((4 * wm + r) * gpt + gl) * 2 + 1] = a.M2;
+            float* o = gbase + ((4 * wm + r) * p.gstat_groups + (cur.n0 + wn * 64 + ni * 32 + lr) / cpg) * 2;
+            o[0] = a.m;
+            o[1] = a.M2;
           }
         }
-      __syncthreads();
-      if (tid < gpt) {  // the 8 rows of the tile, fixed order; each holds 32 pixels x cpg channels
-        const float nrow = 32.f * (float)cpg;
-        MeanM2 a{red2[tid * 2], red2[tid * 2 + 1]};
-#pragma unroll
-        for (int rr = 1; rr < TH; ++rr) a = mm2_merge(a, nrow * (float)rr, MeanM2{red2[(rr * gpt + tid) * 2], red2[(rr * gpt + tid) * 2 + 1]}, nrow);
-        const int tile_in_img = cur.lin - cur.b * (tiles_x * tiles_y);
-        float* o = p.gstat + (((int64_t)cur.b * (tiles_x * tiles_y) + tile_in_img) * p.gstat_groups + cur.n0 / cpg + tid) * 2;
-        o[0] = a.m;
-        o[1] = a.M2;
-      }
-      __syncthreads();
     }
-
     TSTAMP(3);
 #ifdef VAE_WIDE_TIMING
     ++titer;
@@ -505,7 +504,7 @@ int conv3_wide_bf16_gstat_chunks(const vae_igemm_args& a) {
   if (a.gstat_groups <= 0 || a.N % BN != 0 || a.N % a.gstat_groups != 0 || g.mode == VAE_MODE_DGRAD || a.c_step > 1 || a.tapmask != 0) return 0;
   const int cpg = a.N / a.gstat_groups;
   if (cpg != 4 && cpg != 8 && cpg != 16) return 0;
-  return (g.Wo / TW) * (g.Ho / TH);
+  return (g.Wo / TW) * g.Ho;  // one chunk per row of a tile (32 pixels x the group's channels)
 }
 
 template <bool DG, int KS>

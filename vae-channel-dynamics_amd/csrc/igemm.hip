@@ -26,6 +26,7 @@ bool conv3_wino_eligible(const vae_igemm_args& a);                      // conv3
 int launch_wino_weights(const vae_igemm_args& a, float* U, hipStream_t st);
 int launch_conv3_wino(const vae_igemm_args& a, const float* U, hipStream_t st);
 int conv3_wino_gstat_chunks(const vae_igemm_args& a);
+int conv3_tile_bf16_gstat_chunks(const vae_igemm_args& a);
 bool conv3_upwino_eligible(const vae_igemm_args& a);                    // conv3_upwino.hip (fp32 upsampler convolution, 9 positions)
 int launch_upwino_weights(const vae_igemm_args& a, float* U, hipStream_t st);
 int launch_conv3_upwino(const vae_igemm_args& a, const float* U, hipStream_t st);
@@ -894,7 +895,8 @@ extern "C" int vae_conv_gstat_chunks(const vae_igemm_args* ap) {
   const bool bkm = rows_bkm(a), vec = rows_vec(a, bkm);
   if ((a.A16 == nullptr && conv_smallk_eligible(a)) || conv_smalln_eligible(a)) return 0;
   if (rows_use_wide_bf16(a, vec, bkm)) return conv3_wide_bf16_gstat_chunks(a);
-  if (rows_use_tile_bf16(a, vec, bkm) || (a.prec != VAE_PREC_BF16 && rows_use_tile(a, vec, bkm))) return conv3_tile_gstat_chunks(a);
+  if (rows_use_tile_bf16(a, vec, bkm)) return conv3_tile_bf16_gstat_chunks(a);
+  if (a.prec != VAE_PREC_BF16 && rows_use_tile(a, vec, bkm)) return conv3_tile_gstat_chunks(a);
   return 0;
 }
 

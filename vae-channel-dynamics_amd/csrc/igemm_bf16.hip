@@ -263,7 +263,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_rows_bf16_kernel(vae_igemm
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float a0 = p.alpha * acc[mi][ni][2 * j], a1 = p.alpha * acc[mi][ni][2 * j + 1];
-          const float recv = __shfl_xor(odd ? a0 : a1, 1, 64);
+          const float recv = lane_xor1(odd ? a0 : a1);
           typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
           bf16x2_t h;
           h[0] = (__bf16)((odd ? recv : a0) + b0 + __builtin_bit_cast(float, rr[j] << 16));
