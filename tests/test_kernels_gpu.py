@@ -737,7 +737,8 @@ def test_bf16_wide_tile_kernel(cuda, bf16_mode, packed_weights, B, H, W, Ci, Co)
     assert _rel(_nchw(y), y_ref) < 2e-5
     # GroupNorm statistics of the output from the epilogue == statistics of the tensor it wrote
     g2, b2 = torch.ones(Co, device="cuda"), torch.zeros(Co, device="cuda")
-    assert hasattr(y, "_gstat") and y._gstat[2] == H * (W // 32)  # one chunk per 32-pixel row of a tile (both bf16 halo-tile kernels)
+    # chunks: the wide-tile kernel one per 4-row band of a tile, the 128-pixel kernel one per 2-row band
+    assert hasattr(y, "_gstat") and y._gstat[2] == ((H // 4) * (W // 32) if Ci > 128 else (H // 2) * (W // 32))
     st_f = ops.gn_stats(y, g2, b2)
     st_p = ops.gn_stats(y.clone(), g2, b2)
     assert _rel(st_f.mean, st_p.mean) < 1e-5 and _rel(st_f.rstd, st_p.rstd) < 1e-5
@@ -751,7 +752,7 @@ def test_bf16_wide_tile_kernel(cuda, bf16_mode, packed_weights, B, H, W, Ci, Co)
         y0 = ops.conv_fwd(xd, wd, bias.cuda(), "c3", xf=ops.XF_AFFINE_SILU, stats=st, a16=a16, gstat_groups=32)
     finally:
         ops.PROFILER = None
-    assert [r[0] for r in prof.records] == ["conv3_wide_bf16_kernel<false,3>"] and y0._gstat[2] == H * (W // 32)
+    assert [r[0] for r in prof.records] == ["conv3_wide_bf16_kernel<false,3>"] and y0._gstat[2] == (H // 4) * (W // 32)
     assert _rel(_nchw(y0), y_ref - res) < 2e-5
     st_f, st_p = ops.gn_stats(y0, g2, b2), ops.gn_stats(y0.clone(), g2, b2)
     assert _rel(st_f.mean, st_p.mean) < 1e-5 and _rel(st_f.rstd, st_p.rstd) < 1e-5

@@ -392,22 +392,23 @@ __global__ __launch_bounds__(NT, 2) void conv3_tile_bf16_kernel(vae_igemm_args p
         }
       }
     }
-    if (p.gstat) {  // uniform: GroupNorm moments of this tile's outputs, layout of vae_gn_stats_partial with one chunk per ROW of the
-      // tile (32 pixels): written straight from registers, no LDS round trip / barrier (see conv3_wide_bf16.hip)
+    if (p.gstat) {  // uniform: GroupNorm moments of this tile's outputs, layout of vae_gn_stats_partial with one chunk per wave-row
+      // band of the tile (2 rows x 32 pixels): the lane's two rows are merged in place, the group's lanes by DPP moves, and the
+      // first lane writes -- no LDS round trip, no barrier (see conv3_wide_bf16.hip)
       const int cpg = p.N / p.gstat_groups;  // channels per group (4, 8 or 16)
       const int tile_in_img = cur.lin - cur.b * (tiles_x * tiles_y);
-      float* gbase = p.gstat + ((int64_t)cur.b * (tiles_x * tiles_y) + tile_in_img) * TH * p.gstat_groups * 2;
+      float* gbase = p.gstat + (((int64_t)cur.b * (tiles_x * tiles_y) + tile_in_img) * 2 + wm) * p.gstat_groups * 2;
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-          const MeanM2 a = mm2_wave_group(mm2_from_shifted(gpv[mi][ni], gs1[mi][ni], gs2[mi][ni], 16.f), cpg, 16.f);
-          if (lh == 0 && (lr & (cpg - 1)) == 0) {
-            float* o = gbase + ((2 * wm + mi) * p.gstat_groups + (cur.n0 + wn * 64 + ni * 32 + lr) / cpg) * 2;
-            o[0] = a.m;
-            o[1] = a.M2;
-          }
+      for (int ni = 0; ni < 2; ++ni) {
+        const MeanM2 rows = mm2_merge_equal(mm2_from_shifted(gpv[0][ni], gs1[0][ni], gs2[0][ni], 16.f),
+                                            mm2_from_shifted(gpv[1][ni], gs1[1][ni], gs2[1][ni], 16.f), 16.f);
+        const MeanM2 a = mm2_wave_group(rows, cpg, 32.f);
+        if (lh == 0 && (lr & (cpg - 1)) == 0) {
+          float* o = gbase + ((cur.n0 + wn * 64 + ni * 32 + lr) / cpg) * 2;
+          o[0] = a.m;
+          o[1] = a.M2;
         }
+      }
     }
     if (p.track) {  // uniform; the last loop barrier separated the halo reads from this reuse of its space
       float* red = reinterpret_cast<float*>(smem);  // [4 rows][BN] fp32 = 2 KB of the 16 KB halo stage
@@ -446,13 +447,13 @@ void launch_xf(const vae_igemm_args& a, dim3 grid, int tx, int ty, int nt, hipSt
 
 }  // namespace
 
-// chunks per image of the statistics epilogue: one per row of a 4 x 32-pixel tile (0 = not available for these arguments)
+// chunks per image of the statistics epilogue: one per 2-row band of a 4 x 32-pixel tile (0 = not available for these arguments)
 int conv3_tile_bf16_gstat_chunks(const vae_igemm_args& a) {
   const vae_conv_geom& g = a.g;
   if (a.gstat_groups <= 0 || a.N % BN != 0 || a.N % a.gstat_groups != 0 || g.mode == VAE_MODE_DGRAD || a.c_step > 1) return 0;
   const int cpg = a.N / a.gstat_groups;
   if (cpg != 4 && cpg != 8 && cpg != 16) return 0;
-  return (g.Wo / TW) * g.Ho;
+  return (g.Wo / TW) * (g.Ho / 2);
 }
 
 // the kernel reads the weights from their bf16 image in 16-byte (8-element) pieces: they must be aligned and never
