@@ -82,20 +82,13 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
     return id;
   };
 
-  // accumulators [set][output row of the wave][32-channel block].  NSET = 2 would let the epilogue of tile t drain one set between
-  // the MFMA groups of tile t+1 (the stage has the hook: EP0); built and measured in round 3: 256 accumulator registers + the
-  // fragment / staging pipeline exceed the 512-entry register file (270-370 spilled registers), so ONE set and the epilogue runs
-  // between tiles, slimmed down instead (see below)
-  constexpr int NSET = 1;
-  f32x16 acc[NSET][4][2];
+  f32x16 acc[4][2];  // [output row of the wave][32-channel block]
 #pragma unroll
-  for (int st = 0; st < NSET; ++st)
+  for (int r = 0; r < 4; ++r)
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[st][r][ni][e] = 0.f;
+      for (int e = 0; e < 16; ++e) acc[r][ni][e] = 0.f;
 
   // ---------------- staging: global -> registers -> LDS, one piece (16 B per thread) at a time ----------------
   // weight stream: the position of the NEXT stage to request (tile, chunk, kernel column)
@@ -184,7 +177,6 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
   int t = first;
   if (t >= ntiles) return;  // uniform
   Tile cur = decode(t);
-  const Tile cur_init = cur;
   int hpar = 0;  // halo buffer of the chunk being multiplied
 #ifdef VAE_WIDE_SKEW
   // Persistent workgroups with equal tiles run in lockstep: all 256 CUs store their output tiles at the same moment (a burst of
@@ -223,88 +215,6 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
 #pragma unroll
   for (int j = 0; j < NB; ++j) fetch_b(fb[0], j, ringB[0], 0);
 
-  // ---------------- output epilogue as 64 slices (bf16 outputs, KS == 3) ----------------
-  // Adjacent lanes hold adjacent channels of the same 16 pixels: they swap every other register (DPP), so a lane ends up with BOTH
-  // channels of its pair at 8 pixels per 32 x 32 block -- slice K = (block q = K >> 3: row r = q >> 1, channel block ni = q & 1;
-  // pair j = K & 7: pixel 2 j + odd) is one 4-byte store (+ one 4-byte load of the bf16 residual 8 slices earlier, bias of both
-  // channels, GroupNorm moments of the ROUNDED values: the tensor as stored).  Addresses = a per-lane base (2 registers) + a
-  // wave-uniform part in a scalar register.  With one wave per SIMD nothing hides an epilogue behind another wave, and its ~25
-  // VALU instructions per slice plus the statistics merges were 25 % (512 channels) to 40 % (128 channels) of a tile's time
-  // (tools/wide_timing.py: ds_bpermute swaps, per-slice address arithmetic, a tile-level LDS merge with two barriers).
-  const bool odd = lr & 1;
-  const unsigned ldc2 = (unsigned)p.ldc * 2u;
-  Tile prv = cur_init;
-  unsigned plb[2] = {BUF_OOB, BUF_OOB};
-  float pb0[2] = {0.f, 0.f}, pb1[2] = {0.f, 0.f};
-  float egpv[2] = {0.f, 0.f}, egs1[2] = {0.f, 0.f}, egs2[2] = {0.f, 0.f};
-  constexpr int RLEAD = 32;  // residual requests run this many slices ahead of their use (half a tile in flight: the values are HBM-cold)
-  unsigned rres[RLEAD];
-#pragma unroll
-  for (int i = 0; i < RLEAD; ++i) rres[i] = 0u;
-  const size_t ob16 = (size_t)g.Ho * g.Wo * p.ldc * 2u;
-  auto prsC = VAE_BUF_RSRC(p.C, 0);
-  auto prsR = VAE_BUF_RSRC(p.C, 0);
-  auto epi_prepare = [&](const Tile& tl) {  // the tile whose accumulators are complete becomes the one being drained
-    prv = tl;
-    prsC = VAE_BUF_RSRC(reinterpret_cast<u16*>(p.C) + (int64_t)tl.b * g.Ho * g.Wo * p.ldc, ob16);
-    prsR = VAE_BUF_RSRC(reinterpret_cast<const u16*>(p.res ? p.res : p.C) + (int64_t)tl.b * g.Ho * g.Wo * p.ldc, p.res ? ob16 : 0);
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int col = tl.n0 + wn * 64 + ni * 32 + lr;
-      const bool ok = col < p.N;
-      plb[ni] = ok ? (unsigned)((((tl.y0 + 4 * wm) * g.Wo + tl.x0 + 4 * lh + (odd ? 1 : 0)) * p.ldc + (col & ~1)) * 2) : BUF_OOB;
-      pb0[ni] = (p.bias && ok) ? p.bias[col & ~1] : 0.f;
-      pb1[ni] = (p.bias && ok) ? p.bias[col | 1] : 0.f;
-      egpv[ni] = egs1[ni] = egs2[ni] = 0.f;
-    }
-  };
-  auto epi_soff = [&](int r, int j) -> unsigned {  // wave-uniform byte offset of slice (row r, pair j): pixels 2 (j & 1) + 8 (j >> 1) of row r
-    return __builtin_amdgcn_readfirstlane((unsigned)(r * g.Wo + 2 * (j & 1) + 8 * (j >> 1)) * ldc2);
-  };
-  // piece P of the epilogue that drains accumulator set `st`: requests the residual of slice P, writes slice P - RLEAD
-  auto epi_piece = [&](int st, int P) {
-    if (P < 64) {
-      const int q = P >> 3, j = P & 7;
-      rres[P % RLEAD] = __builtin_amdgcn_raw_buffer_load_b32(prsR, plb[q & 1], epi_soff(q >> 1, j), 0);  // (no residual: a zero-sized range reads 0)
-    }
-    if (P >= RLEAD && P < 64 + RLEAD) {
-      const int K = P - RLEAD, q = K >> 3, j = K & 7, r = q >> 1, ni = q & 1;
-      const float a0 = acc[st][r][ni][2 * j], a1 = acc[st][r][ni][2 * j + 1];
-      const float recv = lane_xor1(odd ? a0 : a1);
-      const unsigned rv = rres[K % RLEAD];
-      typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-      bf16x2_t h;
-      h[0] = (__bf16)((odd ? recv : a0) + pb0[ni] + __builtin_bit_cast(float, rv << 16));
-      h[1] = (__bf16)((odd ? a1 : recv) + pb1[ni] + __builtin_bit_cast(float, rv & 0xffff0000u));
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, h), prsC, plb[ni], epi_soff(r, j), 0);
-      const float q0 = (float)h[0], q1 = (float)h[1];
-      if (r == 0 && j == 0) egpv[ni] = q0;  // the lane's first value of channel block ni: pivot of its shifted sums
-      const float d0 = q0 - egpv[ni], d1 = q1 - egpv[ni];
-      egs1[ni] += d0 + d1;
-      egs2[ni] += d0 * d0 + d1 * d1;
-      acc[st][r][ni][2 * j] = 0.f;
-      acc[st][r][ni][2 * j + 1] = 0.f;
-    }
-  };
-  // GroupNorm moments of the drained tile, layout of vae_gn_stats_partial with one chunk per wave-row band (4 rows x 32 pixels): a
-  // lane's 64 values of a channel block belong to one group; the group's lanes are merged by DPP moves and the first lane writes
-  // (no LDS round trip, no barrier: the tile-level merge of round 2 cost 3.5 us per tile)
-  auto epi_stats = [&]() {
-    if (!p.gstat) return;  // uniform
-    const int cpg = p.N / p.gstat_groups;  // channels per group (4, 8 or 16)
-    const int tile_in_img = prv.lin - prv.b * (tiles_x * tiles_y);
-    float* gbase = p.gstat + (((int64_t)prv.b * (tiles_x * tiles_y) + tile_in_img) * 2 + wm) * p.gstat_groups * 2;
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const MeanM2 a = mm2_wave_group(mm2_from_shifted(egpv[ni], egs1[ni], egs2[ni], 64.f), cpg, 64.f);
-      if (lh == 0 && (lr & (cpg - 1)) == 0) {
-        float* o = gbase + ((prv.n0 + wn * 64 + ni * 32 + lr) / cpg) * 2;
-        o[0] = a.m;
-        o[1] = a.M2;
-      }
-    }
-  };
-
   // One stage = block column KWI of the current chunk: 2 k-groups x NPK pieces; a piece = 4 MFMAs (kernel row q >> 1 of the
   // block, output rows 2(q&1), 2(q&1)+1, both channel blocks) followed by its share of the other work of the stage
   // (piece index pi = kg * NPK + q of 2 NPK):
@@ -313,11 +223,9 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
   //   pi < NW            request a piece of weight stage +3 into register set PAR
   //   pi >= 2 NPK - NW   store a piece of weight stage +2 (set PAR^1, requested 1.5 stages ago) into the ring slot stage -1 used
   //   KWI == 0           the first HI pieces request the next chunk's halo;  KWI == 1  the last HI pieces store it
-  auto stage = [&](auto kw_c, auto par_c, auto set_c, auto ep_c) {
+  auto stage = [&](auto kw_c, auto par_c) {
     constexpr int KWI = decltype(kw_c)::value;
     constexpr int PAR = decltype(par_c)::value;  // parity of the stage counter: which weight register set is requested
-    constexpr int SET = decltype(set_c)::value;  // accumulator set of the tile being multiplied
-    constexpr int EP0 = decltype(ep_c)::value;   // >= 0: this stage also runs pieces EP0 .. EP0 + 11 of the previous tile's deferred epilogue
     constexpr int KWN = (KWI + 1) % KS;
     const u16* sH = sHalo + hpar * SH;
     const u16* sHn = (KWI == KS - 1) ? sHalo + (hpar ^ 1) * SH : sH;  // the next stage's halo buffer
@@ -335,8 +243,8 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
         for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni)
-            acc[SET][r0 + rr][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kg][r0 + rr + (DG ? KS - 1 - khi : khi)], fb[kg][khi * 2 + ni],
-                                                                           acc[SET][r0 + rr][ni], 0, 0, 0);
+            acc[r0 + rr][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kg][r0 + rr + (DG ? KS - 1 - khi : khi)], fb[kg][khi * 2 + ni],
+                                                                      acc[r0 + rr][ni], 0, 0, 0);
         if (kg == 0) {
           fetch_a(fa[1], q, sH, KWI, 1);
           if (q == NPK - 1)
@@ -358,7 +266,6 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
         if (pi >= 2 * NPK - NW) w_store_piece(PAR ^ 1, pi - (2 * NPK - NW), sBw);  // stage +2, requested a stage and a half ago
         if (KWI == 0 && pi < HI) h_load_piece(pi);
         if (KWI == 1 && pi >= 2 * NPK - HI) h_store_piece(pi - (2 * NPK - HI), sHw);
-        if (NSET == 2 && EP0 >= 0) epi_piece(SET ^ 1, EP0 + pi);  // one slice of the previous tile's output under this piece's MFMAs
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -387,140 +294,153 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
 #else
 #define TSTAMP(k) do { } while (0)
 #endif
-  constexpr std::integral_constant<int, -1> noep{};
-  // the chunk loop of one tile into accumulator set SET; with `drain` the first two chunks (6 stages = 72 pieces) also carry the
-  // deferred epilogue of the previous tile (set SET ^ 1): 64 residual requests, 64 slices
-  auto run_tile = [&](auto set_c, bool drain) {
+  while (true) {
+    TSTAMP(0);
     if constexpr (KS == 3) {  // 3 stages per chunk: the stage parity repeats every 2 chunks (the launcher checks nch % 2 == 0)
-      int c = 0;
-      if (NSET == 2 && drain) {  // uniform
-        stage(kw0_c, p0, set_c, std::integral_constant<int, 0>{});
-        stage(kw1_c, p1, set_c, std::integral_constant<int, 12>{});
-        stage(kw2_c, p0, set_c, std::integral_constant<int, 24>{});
+      for (int c = 0; c < nch; c += 2) {
+        stage(kw0_c, p0);
+        stage(kw1_c, p1);
+        stage(kw2_c, p0);
         hpar ^= 1;
-        stage(kw0_c, p1, set_c, std::integral_constant<int, 36>{});
-        stage(kw1_c, p0, set_c, std::integral_constant<int, 48>{});
-        stage(kw2_c, p1, set_c, std::integral_constant<int, 60>{});
-        hpar ^= 1;
-        epi_stats();
-        c = 2;
-      }
-      for (; c < nch; c += 2) {
-        stage(kw0_c, p0, set_c, noep);
-        stage(kw1_c, p1, set_c, noep);
-        stage(kw2_c, p0, set_c, noep);
-        hpar ^= 1;
-        stage(kw0_c, p1, set_c, noep);
-        stage(kw1_c, p0, set_c, noep);
-        stage(kw2_c, p1, set_c, noep);
+        stage(kw0_c, p1);
+        stage(kw1_c, p0);
+        stage(kw2_c, p1);
         hpar ^= 1;
       }
     } else {
       for (int c = 0; c < nch; ++c) {
-        stage(kw0_c, p0, set_c, noep);
-        stage(kw1_c, p1, set_c, noep);
+        stage(kw0_c, p0);
+        stage(kw1_c, p1);
         hpar ^= 1;
       }
     }
-  };
-  // the epilogue of accumulator set `st` for tile `tl` right now (nothing follows to hide it behind, or the output is not bf16)
-  auto epilogue_now = [&](auto set_c, const Tile& tl) {
-    constexpr int st = decltype(set_c)::value;
-    if (KS == 3 && p.out_bf16) {  // uniform: the same 64 slices, back to back
-      epi_prepare(tl);
-#pragma unroll
-      for (int P = 0; P < 64 + RLEAD; ++P) epi_piece(st, P);
-      epi_stats();
-      return;
-    }
+
+    // ---------------- epilogue ----------------
+    TSTAMP(1);
     const size_t obytes = (size_t)(g.Ho * cs) * (g.Wo * cs) * p.ldc * 4u;
-    const auto rsC = VAE_BUF_RSRC(p.C + (int64_t)tl.b * (g.Ho * cs) * (g.Wo * cs) * p.ldc, obytes);
-    const auto rsR = VAE_BUF_RSRC((p.res ? p.res : p.C) + (int64_t)tl.b * (g.Ho * cs) * (g.Wo * cs) * p.ldc, obytes);
-    if (p.out_bf16) {  // (KS == 2: a phase convolution of an upsampler: strided output view, no statistics)
-      const size_t o16 = (size_t)(g.Ho * cs) * (g.Wo * cs) * p.ldc * 2u;
-      const auto rsC16 = VAE_BUF_RSRC(reinterpret_cast<u16*>(p.C) + (int64_t)tl.b * (g.Ho * cs) * (g.Wo * cs) * p.ldc, o16);
-      const auto rsR16 = VAE_BUF_RSRC(reinterpret_cast<const u16*>(p.res ? p.res : p.C) + (int64_t)tl.b * (g.Ho * cs) * (g.Wo * cs) * p.ldc, o16);
+    const auto rsC = VAE_BUF_RSRC(p.C + (int64_t)cur.b * (g.Ho * cs) * (g.Wo * cs) * p.ldc, obytes);
+    const auto rsR = VAE_BUF_RSRC((p.res ? p.res : p.C) + (int64_t)cur.b * (g.Ho * cs) * (g.Wo * cs) * p.ldc, obytes);
+    float gs1[4][2], gs2[4][2], gpv[4][2];  // statistics as shifted sums around the lane's first value
+    if (p.out_bf16) {
+      // bf16 output (uniform): adjacent lanes hold adjacent channels of the same 16 pixels; they swap every other register, so a
+      // lane ends up with BOTH channels of its pair at 8 pixels: 4-byte stores, 4-byte loads of the bf16 residual (res_bf16), bias
+      // of both channels.  The statistics epilogue below sums the ROUNDED values (the tensor as stored); a lane's 16 values still
+      // belong to one group, so the group merge is the same as for fp32 outputs.
+      const bool odd = lr & 1;
+      const size_t ob16 = (size_t)(g.Ho * cs) * (g.Wo * cs) * p.ldc * 2u;
+      const auto rsC16 = VAE_BUF_RSRC(reinterpret_cast<u16*>(p.C) + (int64_t)cur.b * (g.Ho * cs) * (g.Wo * cs) * p.ldc, ob16);
+      const auto rsR16 = VAE_BUF_RSRC(reinterpret_cast<const u16*>(p.res ? p.res : p.C) + (int64_t)cur.b * (g.Ho * cs) * (g.Wo * cs) * p.ldc, ob16);
       auto off2 = [&](int r, int ni, int e) -> unsigned {  // byte offset of the lane pair's two channels at pixel e
-        const int oy = tl.y0 + 4 * wm + r, col = tl.n0 + wn * 64 + ni * 32 + lr;
-        const int ox = tl.x0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const int oy = cur.y0 + 4 * wm + r, col = cur.n0 + wn * 64 + ni * 32 + lr;
+        const int ox = cur.x0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
         const bool ok = col < p.N && oy < g.Ho && ox < g.Wo;
-        return ok ? (unsigned)((((oy * cs + p.c_oy) * (g.Wo * cs) + ox * cs + p.c_ox) * p.ldc + (col & ~1)) * 2) : BUF_OOB;
+        if (KS == 2) return ok ? (unsigned)((((oy * cs + p.c_oy) * (g.Wo * cs) + ox * cs + p.c_ox) * p.ldc + (col & ~1)) * 2) : BUF_OOB;
+        return ok ? (unsigned)(((oy * g.Wo + ox) * p.ldc + (col & ~1)) * 2) : BUF_OOB;
       };
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int r = q >> 1, ni = q & 1;
-        const int col = tl.n0 + wn * 64 + ni * 32 + lr;
-        const float b0 = (p.bias && col < p.N) ? p.bias[col & ~1] : 0.f, b1 = (p.bias && col < p.N) ? p.bias[col | 1] : 0.f;
-        unsigned rr[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) rr[j] = p.res ? __builtin_amdgcn_raw_buffer_load_b32(rsR16, off2(r, ni, 2 * j + (odd ? 1 : 0)), 0, 0) : 0u;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float a0 = acc[st][r][ni][2 * j], a1 = acc[st][r][ni][2 * j + 1];
-          const float recv = lane_xor1(odd ? a0 : a1);
-          typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-          bf16x2_t h;
-          h[0] = (__bf16)((odd ? recv : a0) + b0 + __builtin_bit_cast(float, rr[j] << 16));
-          h[1] = (__bf16)((odd ? a1 : recv) + b1 + __builtin_bit_cast(float, rr[j] & 0xffff0000u));
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, h), rsC16, off2(r, ni, 2 * j + (odd ? 1 : 0)), 0, 0);
-          acc[st][r][ni][2 * j] = 0.f;
-          acc[st][r][ni][2 * j + 1] = 0.f;
-        }
-      }
-      return;
-    }
-    // fp32 output (+ bias, + residual).  The residual is HBM-cold: its loads are issued for HALF of the wave's tile (two
-    // rows x two channel blocks, 64 registers) before any of them is consumed -- with one wave per SIMD nothing else hides
-    // that latency; issued per 16-element block they cost 8 round trips per tile (46 % of the 128-channel layers' time)
-    auto offset = [&](int r, int ni, int e) -> unsigned {
-      const int oy = tl.y0 + 4 * wm + r, col = tl.n0 + wn * 64 + ni * 32 + lr;
-      const int ox = tl.x0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-      if (KS == 2)
-        return (col < p.N && oy < g.Ho && ox < g.Wo) ? (unsigned)((((oy * cs + p.c_oy) * (g.Wo * cs) + ox * cs + p.c_ox) * p.ldc + col) * 4) : BUF_OOB;
-      return (col < p.N && oy < g.Ho && ox < g.Wo) ? (unsigned)(((oy * g.Wo + ox) * p.ldc + col) * 4) : BUF_OOB;
-    };
-    prv = tl;
-    egpv[0] = egpv[1] = egs1[0] = egs1[1] = egs2[0] = egs2[1] = 0.f;
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-      float rv[4][16];
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) rv[q][e] = 0.f;
-      if (p.res) {  // uniform
+      for (int hf = 0; hf < 2; ++hf) {
+        unsigned rr[4][8];
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-          for (int e = 0; e < 16; ++e)
-            rv[q][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, offset(2 * hf + (q >> 1), q & 1, e), 0, 0));
+          for (int j = 0; j < 8; ++j) rr[q][j] = 0u;
+        if (p.res) {  // uniform: the residual of half the wave's tile in flight before any of it is consumed
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rr[q][j] = __builtin_amdgcn_raw_buffer_load_b32(rsR16, off2(2 * hf + (q >> 1), q & 1, 2 * j + (odd ? 1 : 0)), 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int r = 2 * hf + (q >> 1), ni = q & 1;
+          const int col = cur.n0 + wn * 64 + ni * 32 + lr;
+          const float b0 = (p.bias && col < p.N) ? p.bias[col & ~1] : 0.f, b1 = (p.bias && col < p.N) ? p.bias[col | 1] : 0.f;
+          gs1[r][ni] = gs2[r][ni] = gpv[r][ni] = 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float a0 = acc[r][ni][2 * j], a1 = acc[r][ni][2 * j + 1];
+            const float recv = lane_xor1(odd ? a0 : a1);
+            typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+            bf16x2_t h;
+            h[0] = (__bf16)((odd ? recv : a0) + b0 + __builtin_bit_cast(float, rr[q][j] << 16));
+            h[1] = (__bf16)((odd ? a1 : recv) + b1 + __builtin_bit_cast(float, rr[q][j] & 0xffff0000u));
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, h), rsC16, off2(r, ni, 2 * j + (odd ? 1 : 0)), 0, 0);
+            const float q0 = (float)h[0], q1 = (float)h[1];
+            if (j == 0) gpv[r][ni] = q0;
+            const float d0 = q0 - gpv[r][ni], d1 = q1 - gpv[r][ni];  // (the statistics epilogue only runs on full tiles)
+            gs1[r][ni] += d0 + d1;
+            gs2[r][ni] += d0 * d0 + d1 * d1;
+            acc[r][ni][2 * j] = 0.f;
+            acc[r][ni][2 * j + 1] = 0.f;
+          }
+        }
       }
+    } else {
+      // fp32 output (+ bias, + residual).  The residual is HBM-cold: its loads are issued for HALF of the wave's tile (two
+      // rows x two channel blocks, 64 registers) before any of them is consumed -- with one wave per SIMD nothing else hides
+      // that latency; issued per 16-element block they cost 8 round trips per tile (46 % of the 128-channel layers' time)
+      auto offset = [&](int r, int ni, int e) -> unsigned {
+        const int oy = cur.y0 + 4 * wm + r, col = cur.n0 + wn * 64 + ni * 32 + lr;
+        const int ox = cur.x0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (KS == 2)
+          return (col < p.N && oy < g.Ho && ox < g.Wo) ? (unsigned)((((oy * cs + p.c_oy) * (g.Wo * cs) + ox * cs + p.c_ox) * p.ldc + col) * 4) : BUF_OOB;
+        return (col < p.N && oy < g.Ho && ox < g.Wo) ? (unsigned)(((oy * g.Wo + ox) * p.ldc + col) * 4) : BUF_OOB;
+      };
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int r = 2 * hf + (q >> 1), ni = q & 1;
-        const int col = tl.n0 + wn * 64 + ni * 32 + lr;
-        const float bv = (p.bias && col < p.N) ? p.bias[col] : 0.f;
+      for (int hf = 0; hf < 2; ++hf) {
+        float rv[4][16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const float v = acc[st][r][ni][e] + bv + rv[q][e];
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, offset(r, ni, e), 0, 0);
-          if (r == 0 && e == 0) egpv[ni] = v;
-          const float dv = v - egpv[ni];  // (the statistics epilogue only runs on full tiles)
-          egs1[ni] += dv;
-          egs2[ni] += dv * dv;
-          acc[st][r][ni][e] = 0.f;
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) rv[q][e] = 0.f;
+        if (p.res) {  // uniform
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+              rv[q][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, offset(2 * hf + (q >> 1), q & 1, e), 0, 0));
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int r = 2 * hf + (q >> 1), ni = q & 1;
+          const int col = cur.n0 + wn * 64 + ni * 32 + lr;
+          const float bv = (p.bias && col < p.N) ? p.bias[col] : 0.f;
+          gs1[r][ni] = gs2[r][ni] = gpv[r][ni] = 0.f;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const float v = acc[r][ni][e] + bv + rv[q][e];
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, offset(r, ni, e), 0, 0);
+            if (e == 0) gpv[r][ni] = v;
+            const float dv = v - gpv[r][ni];  // (the statistics epilogue only runs on full tiles)
+            gs1[r][ni] += dv;
+            gs2[r][ni] += dv * dv;
+            acc[r][ni][e] = 0.f;
+          }
         }
       }
     }
-    if (KS == 3) epi_stats();
-  };
-  constexpr std::integral_constant<int, 0> set0{};
-  while (true) {
-    TSTAMP(0);
-    run_tile(set0, false);
-    TSTAMP(1);
-    epilogue_now(set0, cur);
     TSTAMP(2);
+    if (p.gstat) {  // uniform: centred moments (mean, M2) of this tile's outputs per group, layout of vae_gn_stats_partial with one
+      // chunk per wave-row band of the tile (4 rows x 32 pixels): the lane's four rows are merged in place, the group's lanes by
+      // DPP moves, and the first lane of a group writes -- no LDS round trip, no workgroup barrier (the tile-level merge of round 2
+      // cost 3.5 us per tile, tools/wide_timing.py)
+      const int cpg = p.N / p.gstat_groups;  // channels per group (4, 8 or 16)
+      const int tile_in_img = cur.lin - cur.b * (tiles_x * tiles_y);
+      float* gbase = p.gstat + (((int64_t)cur.b * (tiles_x * tiles_y) + tile_in_img) * 2 + wm) * p.gstat_groups * 2;
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const MeanM2 r01 = mm2_merge_equal(mm2_from_shifted(gpv[0][ni], gs1[0][ni], gs2[0][ni], 16.f),
+                                           mm2_from_shifted(gpv[1][ni], gs1[1][ni], gs2[1][ni], 16.f), 16.f);
+        const MeanM2 r23 = mm2_merge_equal(mm2_from_shifted(gpv[2][ni], gs1[2][ni], gs2[2][ni], 16.f),
+                                           mm2_from_shifted(gpv[3][ni], gs1[3][ni], gs2[3][ni], 16.f), 16.f);
+        const MeanM2 a = mm2_wave_group(mm2_merge_equal(r01, r23, 32.f), cpg, 64.f);
+        if (lh == 0 && (lr & (cpg - 1)) == 0) {
+          float* o = gbase + ((cur.n0 + wn * 64 + ni * 32 + lr) / cpg) * 2;
+          o[0] = a.m;
+          o[1] = a.M2;
+        }
+      }
+    }
     TSTAMP(3);
 #ifdef VAE_WIDE_TIMING
     ++titer;
