@@ -330,13 +330,22 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
       const size_t ob16 = (size_t)(g.Ho * cs) * (g.Wo * cs) * p.ldc * 2u;
       const auto rsC16 = VAE_BUF_RSRC(reinterpret_cast<u16*>(p.C) + (int64_t)cur.b * (g.Ho * cs) * (g.Wo * cs) * p.ldc, ob16);
       const auto rsR16 = VAE_BUF_RSRC(reinterpret_cast<const u16*>(p.res ? p.res : p.C) + (int64_t)cur.b * (g.Ho * cs) * (g.Wo * cs) * p.ldc, ob16);
-      auto off2 = [&](int r, int ni, int e) -> unsigned {  // byte offset of the lane pair's two channels at pixel e
-        const int oy = cur.y0 + 4 * wm + r, col = cur.n0 + wn * 64 + ni * 32 + lr;
-        const int ox = cur.x0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        const bool ok = col < p.N && oy < g.Ho && ox < g.Wo;
-        if (KS == 2) return ok ? (unsigned)((((oy * cs + p.c_oy) * (g.Wo * cs) + ox * cs + p.c_ox) * p.ldc + (col & ~1)) * 2) : BUF_OOB;
-        return ok ? (unsigned)(((oy * g.Wo + ox) * p.ldc + (col & ~1)) * 2) : BUF_OOB;
-      };
+      // byte offset of the lane pair's two channels at pixel e = 2 j + odd of block (r, ni): a per-lane base (the pixel of j = 0) plus
+      // a wave-uniform step -- the tiles are full (eligibility), only a channel beyond N needs masking: its base is 2 GB, beyond any
+      // tensor the 32-bit offsets address, and stays out of range when the step is added.  (The address arithmetic per store was a
+      // quarter of the epilogue's VALU work.)
+      unsigned b2[4][2];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const int oy = cur.y0 + 4 * wm + r, col = cur.n0 + wn * 64 + ni * 32 + lr;
+          const int ox = cur.x0 + (odd ? 1 : 0) + 4 * lh;
+          b2[r][ni] = col < p.N ? (unsigned)((((oy * cs + (KS == 2 ? p.c_oy : 0)) * (g.Wo * cs) + ox * cs + (KS == 2 ? p.c_ox : 0)) * p.ldc + (col & ~1)) * 2)
+                                : 0x80000000u;
+        }
+      const unsigned pstep = (unsigned)(cs * p.ldc * 2);  // bytes per pixel step of the row grid
+      auto off2 = [&](int r, int ni, int e) -> unsigned { return b2[r][ni] + (unsigned)(2 * ((e >> 1) & 1) + 8 * (e >> 2)) * pstep; };
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         unsigned rr[4][8];
