@@ -178,16 +178,6 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
   if (t >= ntiles) return;  // uniform
   Tile cur = decode(t);
   int hpar = 0;  // halo buffer of the chunk being multiplied
-#ifdef VAE_WIDE_SKEW
-  // Persistent workgroups with equal tiles run in lockstep: all 256 CUs store their output tiles at the same moment (a burst of
-  // 16+ MB while HBM idles during the main loops).  Odd workgroups start half a tile late, so only half of the CUs are in
-  // their epilogue at any time.  Only where a workgroup runs many tiles (the idle half tile at the start / end is then cheap).
-  if ((blockIdx.x & 1) && ntiles >= 8 * G) {
-    const long long wait = (long long)nch * KS * 1200 + 9000;  // ~ half a tile in shader-clock ticks
-    const long long t0 = clock64();
-    while (clock64() - t0 < wait) __builtin_amdgcn_s_sleep(32);
-  }
-#endif
 
   // prologue: the first two stages and the first halo into LDS, the third stage into registers
   u16* ringB[3] = {sW, sW + SB, sW + 2 * SB};  // [0] the stage being multiplied, [1] the next one, [2] the one being written
