@@ -84,6 +84,24 @@ __global__ __launch_bounds__(WNT, (NB == 4 ? 2 : 4)) void conv3_wino_kernel(vae_
   __shared__ __attribute__((aligned(16))) float wsm[WINO_LDS / 4];
   float* const sV = wsm;           // [2][SV]
   float* const sH = wsm + 2 * SV;  // [2][SHL]: the chunk's input halo, transformed
+#ifdef VAE_WINO_TIMING  // debug build (tools/wino_timing.py): shader-clock stamps of waves 0 and 4 of workgroups 0..7, per step, into p.track
+  __shared__ unsigned long long sT[2][64][6];
+  __shared__ unsigned long long sE[2][10];  // kernel entry, loop entry, loop exit, per channel block: accumulators in LDS / outputs stored, end
+#define WEDGE(k) do { if ((threadIdx.x & 255) == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); sE[threadIdx.x >> 8][k] = __builtin_amdgcn_s_memtime(); } } while (0)
+#if VAE_WINO_TIMING >= 2  // per-step stamps too (more intrusive: every stamp waits for the wave's LDS operations)
+#define WSTAMP(k) do { if ((threadIdx.x & 255) == 0 && wts < 64) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); sT[threadIdx.x >> 8][wts][k] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define WSTAMP(k) do { } while (0)
+#endif
+  int wts = 0;
+#else
+#define WSTAMP(k) do { } while (0)
+#define WEDGE(k) do { } while (0)
+#endif
+  WEDGE(0);
+#ifdef VAE_WINO_TIMING
+  if ((threadIdx.x & 255) == 0) sE[threadIdx.x >> 8][8] = __builtin_amdgcn_s_memrealtime();  // 100 MHz: the in-kernel clock is d(memtime) / d(memrealtime) x 100 MHz
+#endif
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
@@ -245,21 +263,35 @@ __global__ __launch_bounds__(WNT, (NB == 4 ? 2 : 4)) void conv3_wino_kernel(vae_
 #pragma unroll
       for (int pi = 0; pi < 2; ++pi) a4[pi] = *reinterpret_cast<const f32x4*>(&cV[((2 * wave + pi) * NTL + lr) * WBK + 4 * lh]);
     };
+    WSTAMP(0);
     load_b(s + 1, nxt);
     __builtin_amdgcn_sched_barrier(0);
+    WSTAMP(1);
     if (wave < 4) {  // uniform per wave
       stage_next(s, par);
+      WSTAMP(2);
       read_a();
       __builtin_amdgcn_sched_barrier(0);
+      WSTAMP(3);
       multiply(a4, cur);
+      __builtin_amdgcn_sched_barrier(0);
+      WSTAMP(4);
     } else {
       read_a();
+      WSTAMP(2);
       multiply(a4, cur);
       __builtin_amdgcn_sched_barrier(0);
+      WSTAMP(3);
       stage_next(s, par);
+      WSTAMP(4);
     }
     __syncthreads();
+    WSTAMP(5);
+#ifdef VAE_WINO_TIMING
+    ++wts;
+#endif
   };
+  WEDGE(1);
   {
     int s = 0;
     for (; s + 1 < nsteps; s += 2) {
@@ -269,6 +301,13 @@ __global__ __launch_bounds__(WNT, (NB == 4 ? 2 : 4)) void conv3_wino_kernel(vae_
     if (s < nsteps) step(s, 0, bq0, bq1);
   }
 
+  WEDGE(2);
+#if defined(VAE_WINO_TIMING) && VAE_WINO_TIMING >= 2
+  if (p.track && blockIdx.x < 8 && (tid & 255) < 64) {  // [workgroup][wave 0 / 4][step][6] as uint64; entry [.][.][63][5] = end of the kernel (below)
+    unsigned long long* out = reinterpret_cast<unsigned long long*>(p.track) + (blockIdx.x * 2 + (tid >> 8)) * 64 * 6;
+    for (int i = tid & 255; i < 64 * 6; i += 64) out[i] = (i / 6 < wts) ? sT[tid >> 8][i / 6][i % 6] : 0ull;
+  }
+#endif
   // ---- epilogue: per 32-channel block, M through LDS, then Y = A^T M A ----
   float* const sM = wsm;  // [16][32 tiles][SMLD], over the V / halo buffers (the last step's barrier has passed)
   const size_t obytes = (size_t)g.Ho * g.Wo * p.ldc * 4u;
@@ -302,6 +341,7 @@ __global__ __launch_bounds__(WNT, (NB == 4 ? 2 : 4)) void conv3_wino_kernel(vae_
       }
     }
     __syncthreads();
+    WEDGE(3 + 2 * nb);
     float gpv = 0.f, gs1 = 0.f, gs2 = 0.f;  // GroupNorm statistics of this thread's 8 outputs of channel `col`: shifted sums
 #pragma unroll
     for (int rnd = 0; rnd < 2; ++rnd) {
@@ -333,6 +373,7 @@ __global__ __launch_bounds__(WNT, (NB == 4 ? 2 : 4)) void conv3_wino_kernel(vae_
         }
       }
     }
+    WEDGE(4 + 2 * nb);
     float* const red = sM + 16 * NTL * SMLD;  // [8 waves][groups of the 32-channel block][2]
     const int cpg = p.gstat ? p.N / p.gstat_groups : 4, ng = 32 / cpg;
     if (p.gstat) {  // uniform: centred moments of the block's groups; a wave holds 2 tile slots x 32 channels
@@ -353,6 +394,12 @@ __global__ __launch_bounds__(WNT, (NB == 4 ? 2 : 4)) void conv3_wino_kernel(vae_
       o[1] = a.M2;
     }
   }
+#ifdef VAE_WINO_TIMING
+  WEDGE(7);
+  if ((tid & 255) == 0) sE[tid >> 8][9] = __builtin_amdgcn_s_memrealtime();
+  if (p.track && blockIdx.x < 8 && (tid & 255) < 10)
+    reinterpret_cast<unsigned long long*>(p.track)[8 * 2 * 64 * 6 + (blockIdx.x * 2 + (tid >> 8)) * 10 + (tid & 255)] = sE[tid >> 8][tid & 255];
+#endif
 }
 
 }  // namespace
@@ -362,7 +409,10 @@ bool conv3_wino_eligible(const vae_igemm_args& a) {
   const vae_conv_geom& g = a.g;
   if (a.prec != VAE_PREC_F32 || a.A16 != nullptr || a.batch != 1 || a.alpha != 1.0f) return false;
   if (g.taps != 9 || g.stride != 1 || g.pad_t != 1 || g.pad_l != 1) return false;
-  if (a.tapmask != 0 || a.a_step > 1 || a.c_step > 1 || a.track != nullptr || a.out_bf16) return false;
+  if (a.tapmask != 0 || a.a_step > 1 || a.c_step > 1 || a.out_bf16) return false;
+#ifndef VAE_WINO_TIMING  // (the instrumented build writes its stamps through `track`)
+  if (a.track != nullptr) return false;
+#endif
   if (!(g.mode == VAE_MODE_FWD || g.mode == VAE_MODE_DGRAD) || g.Ho != g.Hs || g.Wo != g.Ws) return false;
   if (g.mode == VAE_MODE_DGRAD && a.xf != VAE_XF_NONE) return false;
   if (g.Ho % WTH != 0 || g.Wo % WTW != 0 || a.K % WBK != 0 || a.K < 64 || a.K > 1024 || a.N < 32 || a.N % 4 != 0 || g.Cs < a.K) return false;
