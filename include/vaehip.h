@@ -123,8 +123,22 @@ typedef struct vae_igemm_args {
   int32_t a_bf16;        /* A itself is a bf16 tensor (same layout) and xf still applies: the flat and the <= 4-channel kernels.
                           * (A16 is the other case: an already transformed image next to / instead of A, xf == NONE.)          */
   int32_t res_bf16;      /* res is a bf16 tensor                                                                               */
+  /* GroupNorm-backward partial sums from a DGRAD epilogue (all zero = off; vae_conv_gnb_chunks(a) > 0): the launch computes
+   * dA = dL/d silu(gn(x)) (gnb_silu) or dL/d gn(x); with the GroupNorm input x (same [B,Ho,Wo,N] shape and ldc as C, stored
+   * fp32 or bf16), its statistics and affine parameters the epilogue also leaves what vae_gn_bwd_partial would compute from
+   * (x, dA) in a separate pass over both tensors: gnb_ws[b][chunk][N][2] = (sum dz, sum dz * xhat) per output tile, dz = dA *
+   * silu'(gamma * xhat + beta) -- vae_gn_bwd_final(nchunk = chunks) finishes it.  (reference: the autograd backward of
+   * diffusers' ResnetBlock2D norm -> nonlinearity -> conv, call sites src/models/sdxl_vae_wrapper.py:60,71)               */
+  const void* gnb_x;
+  const float* gnb_mean; const float* gnb_rstd;   /* [B][gnb_groups] */
+  const float* gnb_gamma; const float* gnb_beta;  /* [N]             */
+  float* gnb_ws;
+  int32_t gnb_groups, gnb_silu, gnb_x_bf16;
 } vae_igemm_args;
 int vae_igemm_rows(const vae_igemm_args* a, void* stream);
+/* chunks per image the launch for `a` (gnb_x .. gnb_groups set) would write into a->gnb_ws, or 0 when the kernel serving it
+ * has no GroupNorm-backward epilogue (the caller then runs vae_gn_bwd_partial)                                       */
+int vae_conv_gnb_chunks(const vae_igemm_args* a);
 /* number of chunks per image the launch for `a` (with a->gstat_groups set) would write into a->gstat, or 0 when the
  * kernel serving it has no statistics epilogue (the caller then runs vae_gn_stats_partial on the output)           */
 int vae_conv_gstat_chunks(const vae_igemm_args* a);

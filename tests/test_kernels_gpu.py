@@ -872,6 +872,47 @@ def test_winograd_forward_and_dgrad(cuda, B, H, W, Ci, Co):
     assert torch.equal(ops.conv_fwd(xd, wd, bias.cuda(), "c3"), y0)
 
 
+@pytest.mark.parametrize("B,H,W,Ci,Co,silu", [(2, 16, 32, 128, 64, True), (1, 24, 16, 256, 128, True), (2, 8, 16, 128, 192, False)])
+def test_winograd_dgrad_leaves_groupnorm_backward_sums(cuda, B, H, W, Ci, Co, silu):
+    """dgrad epilogue with gnb_*: the per-tile sums it leaves make gn_bwd (without its first pass) return what the three-pass
+    form returns from the same tensors, and what autograd returns for silu(gn(x)) -> conv"""
+    from vaehip import ops
+    gen = torch.Generator().manual_seed(47 + Ci + Co + H)
+    x = torch.randn(B, Ci, H, W, generator=gen) * 1.3 + 0.2
+    w = torch.randn(Co, Ci, 3, 3, generator=gen) / math.sqrt(9 * Ci)
+    dy = torch.randn(B, Co, H, W, generator=gen)
+    gamma, beta = 1 + 0.3 * torch.randn(Ci, generator=gen), 0.2 * torch.randn(Ci, generator=gen)
+    xd, wd, dyd = _nhwc(x), _to_dev_ohwi(w), _nhwc(dy)
+    gd, bd = gamma.cuda(), beta.cuda()
+    st = ops.gn_stats(xd, gd, bd)
+    ctx = ops.GnCtx(xd, st, gd, bd, silu, 32)
+
+    def bwd(dA):
+        dg, db = torch.full((Ci,), float("nan"), device="cuda"), torch.full((Ci,), float("nan"), device="cuda")
+        return ops.gn_bwd(xd, dA, st, gd, bd, silu, None, dg, db), dg, db
+
+    prof = ops.PROFILER = ops.LaunchProfiler()
+    try:
+        dA_f = ops.conv_dgrad(dyd, wd, "c3", (H, W), gnb=ctx)
+    finally:
+        ops.PROFILER = None
+    assert [r[0] for r in prof.records] == ["conv3_wino_kernel<0,2>"]
+    assert hasattr(dA_f, "_gnb") and dA_f._gnb[1] == (H // 8) * (W // 16)
+    dA_p = ops.conv_dgrad(dyd, wd, "c3", (H, W))
+    assert torch.equal(dA_f, dA_p) and not hasattr(dA_p, "_gnb")  # the epilogue does not touch the gradient itself
+    (dx_f, dg_f, db_f), (dx_p, dg_p, db_p) = bwd(dA_f), bwd(dA_p)
+    assert _rel(dx_f, dx_p) < 2e-6 and _rel(dg_f, dg_p) < 2e-6 and _rel(db_f, db_p) < 2e-6
+    assert torch.equal(bwd(ops.conv_dgrad(dyd, wd, "c3", (H, W), gnb=ctx))[0], dx_f)  # deterministic
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    h = F.group_norm(xr, 32, gr, br, 1e-6)
+    F.conv2d(F.silu(h) if silu else h, w, None, 1, 1).backward(dy)
+    assert _rel(_nchw(dx_f), xr.grad) < 2e-5 and _rel(dg_f.cpu(), gr.grad) < 2e-5 and _rel(db_f.cpu(), br.grad) < 2e-5
+    # a gradient tensor that is not this GroupNorm's (another x) falls back to the first pass
+    other = xd.clone()
+    dg, db = torch.empty(Ci, device="cuda"), torch.empty(Ci, device="cuda")
+    assert torch.equal(ops.gn_bwd(other, dA_f, st, gd, bd, silu, None, dg, db), dx_p)
+
+
 # (B,H,W,Ci,Co): several strips per row and rows per image, several images per split, Ci / Co blocks, a single unit row
 WINO_WGRAD_CASES = [(2, 32, 32, 128, 128), (1, 64, 64, 256, 128), (3, 16, 32, 512, 256), (5, 6, 48, 128, 128), (1, 2, 16, 128, 128)]
 

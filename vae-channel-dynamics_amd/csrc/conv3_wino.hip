@@ -38,9 +38,9 @@ constexpr int SV = 16 * NTL * WBK;        // floats per V buffer (16384 B): rows
                                           // cover 1 KB contiguously and the transform's 4-byte writes are thread-contiguous
 constexpr int SMLD = 33;                  // epilogue image row (floats)
 constexpr int SHL = 180 * WBK;            // floats per halo buffer (10 x 18 pixels x 8 channels, 5760 B)
-constexpr int SM = 16 * NTL * SMLD + 8 * 8 * 2;  // epilogue image + statistics scratch; overlays the V / halo buffers
+constexpr int SM = 16 * NTL * SMLD + 8 * 8 * 2 + 16 * 32 * 2;  // epilogue image + statistics scratch + GroupNorm-backward sums; overlays the V / halo buffers
 constexpr int WSS = 2 * 1024;             // GroupNorm scale / shift rows of the image (K <= 1024)
-constexpr int WINO_LDS = (SM > 2 * SV + 2 * SHL + WSS ? SM : 2 * SV + 2 * SHL + WSS) * 4;  // 68096 B
+constexpr int WINO_LDS = (SM > 2 * SV + 2 * SHL + WSS ? SM : 2 * SV + 2 * SHL + WSS) * 4;  // 72192 B
 
 // U[pos][n][k] = (G g G^T)[pos] for g = W[n][.][.][k] (forward, N = Cout, K = Cin) or g = rot180(W[k][.][.][n]) (dgrad,
 // N = Cin, K = Cout); output layout [K/8][16][N][8]
@@ -313,6 +313,11 @@ __global__ __launch_bounds__(WNT, (NB == 4 ? 2 : 4)) void conv3_wino_kernel(vae_
   const size_t obytes = (size_t)g.Ho * g.Wo * p.ldc * 4u;
   const auto rsC = VAE_BUF_RSRC(p.C + (int64_t)b * g.Ho * g.Wo * p.ldc, obytes);
   const auto rsR = VAE_BUF_RSRC((p.res ? p.res : p.C) + (int64_t)b * g.Ho * g.Wo * p.ldc, obytes);
+  // GroupNorm-backward epilogue (dgrad launches, vaehip.h gnb_*): x at this thread's output positions, stored fp32 or bf16
+  const bool gnb = p.gnb_ws != nullptr;  // uniform
+  const unsigned xes = p.gnb_x_bf16 ? 2u : 4u;
+  const auto rsX = VAE_BUF_RSRC(reinterpret_cast<const char*>(gnb ? p.gnb_x : (const void*)p.C) + (int64_t)b * g.Ho * g.Wo * p.ldc * xes,
+                                (size_t)g.Ho * g.Wo * p.ldc * xes);
   // byte offsets of this thread's 8 outputs per channel block (2 tile slots x 2 x 2 pixels, channel n0 + (tid & 31))
   unsigned offp[8];
 #pragma unroll
@@ -331,6 +336,15 @@ __global__ __launch_bounds__(WNT, (NB == 4 ? 2 : 4)) void conv3_wino_kernel(vae_
       off[q] = (cok && offp[q] != BUF_OOB) ? offp[q] + nb * 128u : BUF_OOB;
       rres[q] = p.res ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, off[q], 0, 0)) : 0.f;
     }
+    float xin[8];  // the GroupNorm input at the same 8 positions (requested here, used after the LDS round trip)
+    if (gnb) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const unsigned eo = off[q] == BUF_OOB ? BUF_OOB : (p.gnb_x_bf16 ? off[q] >> 1 : off[q]);
+        xin[q] = p.gnb_x_bf16 ? __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rsX, eo, 0, 0) << 16)
+                              : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX, eo, 0, 0));
+      }
+    }
 #pragma unroll
     for (int pi = 0; pi < 2; ++pi) {
       const int pos = 2 * wave + pi;
@@ -343,6 +357,16 @@ __global__ __launch_bounds__(WNT, (NB == 4 ? 2 : 4)) void conv3_wino_kernel(vae_
     __syncthreads();
     WEDGE(3 + 2 * nb);
     float gpv = 0.f, gs1 = 0.f, gs2 = 0.f;  // GroupNorm statistics of this thread's 8 outputs of channel `col`: shifted sums
+    float bs1 = 0.f, bs2 = 0.f;             // GroupNorm backward: sum dz, sum dz * xhat over the same 8 outputs
+    float bmu = 0.f, brs = 0.f, bga = 0.f, bbe = 0.f;
+    if (gnb) {
+      const int colb = min(n0 + nb * 32 + (tid & 31), p.N - 1);
+      const int grp = colb / (p.N / p.gnb_groups);
+      bmu = p.gnb_mean[b * p.gnb_groups + grp];
+      brs = p.gnb_rstd[b * p.gnb_groups + grp];
+      bga = p.gnb_gamma[colb];
+      bbe = p.gnb_beta[colb];
+    }
 #pragma unroll
     for (int rnd = 0; rnd < 2; ++rnd) {
       const int co = tid & 31, tile = (tid >> 5) + 16 * rnd;
@@ -370,11 +394,23 @@ __global__ __launch_bounds__(WNT, (NB == 4 ? 2 : 4)) void conv3_wino_kernel(vae_
           const float dv = v - gpv;  // (the statistics epilogue only runs on full tiles)
           gs1 += dv;
           gs2 += dv * dv;
+          if (gnb) {  // uniform; same arithmetic per element as gn_bwd_partial_kernel (norm.hip)
+            const float xh = (xin[q] - bmu) * brs;
+            float du = v;
+            if (p.gnb_silu) du *= silu_grad_f(xh * bga + bbe);
+            bs1 += du;
+            bs2 += du * xh;
+          }
         }
       }
     }
     WEDGE(4 + 2 * nb);
     float* const red = sM + 16 * NTL * SMLD;  // [8 waves][groups of the 32-channel block][2]
+    float* const redb = red + 8 * 8 * 2;      // [16 tile slots][32 channels][2]
+    if (gnb) {
+      redb[((tid >> 5) * 32 + (tid & 31)) * 2] = bs1;
+      redb[((tid >> 5) * 32 + (tid & 31)) * 2 + 1] = bs2;
+    }
     const int cpg = p.gstat ? p.N / p.gstat_groups : 4, ng = 32 / cpg;
     if (p.gstat) {  // uniform: centred moments of the block's groups; a wave holds 2 tile slots x 32 channels
       const MeanM2 a = mm2_wave_group(mm2_from_shifted(gpv, gs1, gs2, 8.f), cpg, 8.f);
@@ -384,6 +420,17 @@ __global__ __launch_bounds__(WNT, (NB == 4 ? 2 : 4)) void conv3_wino_kernel(vae_
       }
     }
     __syncthreads();
+    if (gnb && tid < 32 && n0 + nb * 32 + tid < p.N) {  // the 16 tile slots of a channel, fixed order
+      float a1 = redb[tid * 2], a2 = redb[tid * 2 + 1];
+#pragma unroll
+      for (int w = 1; w < 16; ++w) {
+        a1 += redb[(w * 32 + tid) * 2];
+        a2 += redb[(w * 32 + tid) * 2 + 1];
+      }
+      float* o = p.gnb_ws + (((int64_t)b * (tiles_x * tiles_y) + ty * tiles_x + tx) * p.N + n0 + nb * 32 + tid) * 2;
+      o[0] = a1;
+      o[1] = a2;
+    }
     if (p.gstat && tid < ng) {  // the 8 waves (16 outputs x cpg channels each), fixed order
       const float nw = 16.f * (float)cpg;
       MeanM2 a{red[tid * 2], red[tid * 2 + 1]};
@@ -432,6 +479,16 @@ int conv3_wino_gstat_chunks(const vae_igemm_args& a) {
   if (a.gstat_groups <= 0 || a.N % (32 * conv3_wino_nb()) != 0 || a.N % a.gstat_groups != 0 || g.mode == VAE_MODE_DGRAD) return 0;
   const int cpg = a.N / a.gstat_groups;
   if (cpg != 4 && cpg != 8 && cpg != 16) return 0;
+  return (g.Wo / WTW) * (g.Ho / WTH);
+}
+
+// chunks per image of the GroupNorm-backward epilogue (0 = not available for these arguments): full tiles of a dgrad launch
+// whose output has the GroupNorm input's shape
+int conv3_wino_gnb_chunks(const vae_igemm_args& a) {
+  const vae_conv_geom& g = a.g;
+  if (g.mode != VAE_MODE_DGRAD || a.gnb_x == nullptr || a.gnb_groups <= 0 || a.N % a.gnb_groups != 0 || a.ldc != a.N) return 0;
+  if (a.res != nullptr || a.bias != nullptr || a.out_bf16) return 0;
+  if ((size_t)g.Ho * g.Wo * a.ldc * 4u >= BUF_MAX) return 0;
   return (g.Wo / WTW) * (g.Ho / WTH);
 }
 

@@ -26,6 +26,7 @@ bool conv3_wino_eligible(const vae_igemm_args& a);                      // conv3
 int launch_wino_weights(const vae_igemm_args& a, float* U, hipStream_t st);
 int launch_conv3_wino(const vae_igemm_args& a, const float* U, hipStream_t st);
 int conv3_wino_gstat_chunks(const vae_igemm_args& a);
+int conv3_wino_gnb_chunks(const vae_igemm_args& a);
 int conv3_tile_bf16_gstat_chunks(const vae_igemm_args& a);
 bool conv3_upwino_eligible(const vae_igemm_args& a);                    // conv3_upwino.hip (fp32 upsampler convolution, 9 positions)
 int launch_upwino_weights(const vae_igemm_args& a, float* U, hipStream_t st);
@@ -888,6 +889,13 @@ extern "C" int vae_conv_phase_ok(const vae_igemm_args* ap) {
   if (a.prec == VAE_PREC_BF16) return (a.xf == VAE_XF_NONE && rows_use_tile_bf16(a, vec, bkm)) ? 1 : 0;  // no transform variant there
   return rows_use_tile(a, vec, bkm) ? 1 : 0;
 }
+extern "C" int vae_conv_gnb_chunks(const vae_igemm_args* ap) {
+  if (!ap) return 0;
+  const vae_igemm_args a = rows_canon(*ap);
+  if (a.Wu != nullptr && rows_wino(a)) return conv3_wino_gnb_chunks(a);
+  return 0;  // (the other dgrad kernels have no such epilogue yet)
+}
+
 extern "C" int vae_conv_gstat_chunks(const vae_igemm_args* ap) {
   if (!ap) return 0;
   const vae_igemm_args a = rows_canon(*ap);
@@ -973,6 +981,8 @@ extern "C" int vae_igemm_rows(const vae_igemm_args* ap, void* stream) {
   const bool bkm = rows_bkm(a);
   const bool vec = rows_vec(a, bkm);
   VAE_CHECK(a.gstat == nullptr || vae_conv_gstat_chunks(ap) > 0, "igemm_rows: no statistics epilogue for these arguments (vae_conv_gstat_chunks)");
+  VAE_CHECK(a.gnb_ws == nullptr || vae_conv_gnb_chunks(ap) > 0, "igemm_rows: no GroupNorm-backward epilogue for these arguments (vae_conv_gnb_chunks)");
+  VAE_CHECK(a.gnb_ws == nullptr || (a.gnb_mean && a.gnb_rstd && a.gnb_gamma && a.gnb_beta && aligned16(a.gnb_x)), "igemm_rows: gnb_* pointers");
   VAE_CHECK(rows_io16_ok(a), "igemm_rows: the kernel serving these arguments does not take this combination of out_bf16 / a_bf16 / res_bf16 (vae_conv_io16_ok)");
   hipStream_t st = (hipStream_t)stream;
   VAE_CHECK(a.g.mode != VAE_MODE_UP2X_DGRAD || a.Wu != nullptr, "igemm_rows: UP2X_DGRAD exists only as the Winograd-type kernel (vae_wino_ok, Wu)");

@@ -234,11 +234,16 @@ class Engine:
         a16, self._last16 = self._last16, None
         return a16 if recording else None
 
-    def _conv_bwd(self, m, x, dy, xf, st, need_dx=True, x16=None, dx_to_gn=False, dx_dtype=None):
+    def _conv_bwd(self, m, x, dy, xf, st, need_dx=True, x16=None, dx_to_gn=False, dx_dtype=None, norm=None):
         """dy: fp32 (possibly carrying a bf16 image) or bf16; dx_to_gn: the input gradient goes to a GroupNorm backward and
         nowhere else, so bf16 mode may store it as bf16 even with fp32 activation storage; dx_dtype: storage of the input
         gradient when the default (ops.conv_dgrad) is not wanted"""
         kind = getattr(m, "kind", "c1")
+        # norm: the GroupNorm(+SiLU) between x and this convolution, whose backward consumes the input gradient next: the dgrad
+        # epilogue can leave that backward's first pass (ops.conv_dgrad gnb)
+        gnb = None
+        if norm is not None and need_dx and st is not None and xf in (XF_AFFINE, XF_AFFINE_SILU):
+            gnb = ops.GnCtx(x, st, norm.weight, norm.bias, xf == XF_AFFINE_SILU, norm.num_groups)
         if (need_dx and dy.dtype == torch.float32 and getattr(dy, "_b16", None) is None
                 and ops.grad_image_ok(kind, x.shape[:3] + (m.weight.shape[1],), m.weight.shape[0], m.weight.shape[1])):
             # a gradient that arrives without its bf16 image (from an upsampler, an attention block, the loss): rounding it
@@ -248,7 +253,7 @@ class Engine:
             x, xf, st, x16 = x16, XF_NONE, None, None
         ops.conv_wgrad(dy, x, kind, self._g(m.weight), self._g(m.bias), xf=xf, stats=st, x16=x16)
         if need_dx:
-            return ops.conv_dgrad(dy, m.weight, kind, (x.shape[1], x.shape[2]), out_bf16=dx_to_gn, out_dtype=dx_dtype)
+            return ops.conv_dgrad(dy, m.weight, kind, (x.shape[1], x.shape[2]), out_bf16=dx_to_gn, out_dtype=dx_dtype, gnb=gnb)
         return None
 
     def _gn_bwd(self, norm, x, g, st, silu, add, conv_only=None, feeds_conv3=False):
@@ -313,9 +318,9 @@ class Engine:
         self._post(r, lambda: x, out)
         if tape is not None:
             def bwd(dout):
-                g2 = self._conv_bwd(r.conv2, h, dout, XF_AFFINE_SILU, st2, x16=h16, dx_to_gn=True)
+                g2 = self._conv_bwd(r.conv2, h, dout, XF_AFFINE_SILU, st2, x16=h16, dx_to_gn=True, norm=r.norm2)
                 dh = self._gn_bwd(r.norm2, h, g2, st2, True, None, conv_only=r.conv1)  # dL/dh only feeds conv1's wgrad + dgrad
-                g1 = self._conv_bwd(r.conv1, x, dh, XF_AFFINE_SILU, st1, x16=x16, dx_to_gn=True)
+                g1 = self._conv_bwd(r.conv1, x, dh, XF_AFFINE_SILU, st1, x16=x16, dx_to_gn=True, norm=r.norm1)
                 dsc = self._conv_bwd(r.conv_shortcut, x, dout, XF_NONE, None) if r.conv_shortcut is not None else dout
                 dx = self._gn_bwd(r.norm1, x, g1, st1, True, dsc, feeds_conv3=after_conv3)
                 if notify is True:
@@ -414,7 +419,7 @@ class Engine:
         x16 = self._take16(tape is not None)
         if tape is not None:
             def bwd(d):
-                g = self._conv_bwd(conv, x, d, XF_AFFINE_SILU, st, x16=x16, dx_to_gn=True)
+                g = self._conv_bwd(conv, x, d, XF_AFFINE_SILU, st, x16=x16, dx_to_gn=True, norm=norm)
                 dx = self._gn_bwd(norm, x, g, st, True, None, feeds_conv3=True)
                 self._done(conv)
                 self._done(norm)

@@ -31,7 +31,9 @@ class IgemmArgs(C.Structure):
                 ("tapmask", C.c_int32), ("a_step", C.c_int32), ("a_oy", C.c_int32), ("a_ox", C.c_int32),
                 ("c_step", C.c_int32), ("c_oy", C.c_int32), ("c_ox", C.c_int32),
                 ("gstat", _fp), ("gstat_groups", C.c_int32), ("Wu", _fp), ("out_bf16", C.c_int32),
-                ("a_bf16", C.c_int32), ("res_bf16", C.c_int32)]
+                ("a_bf16", C.c_int32), ("res_bf16", C.c_int32),
+                ("gnb_x", _fp), ("gnb_mean", _fp), ("gnb_rstd", _fp), ("gnb_gamma", _fp), ("gnb_beta", _fp), ("gnb_ws", _fp),
+                ("gnb_groups", C.c_int32), ("gnb_silu", C.c_int32), ("gnb_x_bf16", C.c_int32)]
 
 
 class WgradArgs(C.Structure):
@@ -44,7 +46,7 @@ class WgradArgs(C.Structure):
 
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
-EXPECTED_ABI = 10  # vae_abi_version() of the library these structures and signatures describe
+EXPECTED_ABI = 11  # vae_abi_version() of the library these structures and signatures describe
 
 # name -> argtypes (every function returns int); must list EVERY symbol of include/vaehip.h
 SIGNATURES = {
@@ -52,6 +54,7 @@ SIGNATURES = {
     "vae_get_option": [C.c_char_p],
     "vae_igemm_rows": [C.POINTER(IgemmArgs), vp],
     "vae_conv_gstat_chunks": [C.POINTER(IgemmArgs)],
+    "vae_conv_gnb_chunks": [C.POINTER(IgemmArgs)],
     "vae_conv_phase_ok": [C.POINTER(IgemmArgs)],
     "vae_conv_io16_ok": [C.POINTER(IgemmArgs)],
     "vae_wgrad_io16_ok": [C.POINTER(WgradArgs)],

@@ -583,9 +583,24 @@ def conv_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], kin
     return out
 
 
+GNB_EPILOGUE = True  # GroupNorm-backward partial sums from the dgrad epilogue where the serving kernel has one (vae_conv_gnb_chunks)
+
+
+class GnCtx(NamedTuple):
+    """the GroupNorm (+SiLU) whose output the convolution read: what its backward needs besides dL/d(output)"""
+    x: torch.Tensor       # the GroupNorm input, NHWC, as stored
+    st: "Stats"
+    gamma: torch.Tensor
+    beta: torch.Tensor
+    silu: bool
+    groups: int
+
+
 def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, kind: str, in_hw: Tuple[int, int], out_bf16: bool = False,
-               out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+               out_dtype: Optional[torch.dtype] = None, gnb: Optional[GnCtx] = None) -> torch.Tensor:
     """gradient wrt the conv input (the XF'ed tensor); dy [B,Ho,Wo,Co] -> [B,H,W,Ci].
+    gnb: the result is dL/d silu(gn(x)) of this GroupNorm and goes to gn_bwd: where the kernel serving the launch can, its
+    epilogue also leaves gn_bwd's first pass (the per-chunk sums over x and the result), attached as `_gnb = (ws, nchunk)`.
     dy: fp32 (optionally with a bf16 image attached, `_b16`) or a bf16 tensor.  Storage of the result: out_dtype, or bf16 when
     act16() and Ci >= ACT16_MIN_C, or when out_bf16 is asked for and the halo-tile kernel serving the layer can write it (fp32
     storage mode: the caller feeds it to gn_bwd only), else fp32."""
@@ -642,6 +657,17 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, kind: str, in_hw: Tuple[int, i
     out = torch.empty((B, Hr, Wr, Ci), device=src.device, dtype=torch.bfloat16 if o16 else torch.float32)
     a.C = _p(out)
     wu = _wino(a, src.device)
+    if gnb is not None and GNB_EPILOGUE and not pool and gnb.x.shape == out.shape:
+        a.gnb_x, a.gnb_x_bf16 = _p(gnb.x), _b16(gnb.x)
+        a.gnb_mean, a.gnb_rstd, a.gnb_gamma, a.gnb_beta = _p(gnb.st.mean), _p(gnb.st.rstd), _p(gnb.gamma), _p(gnb.beta)
+        a.gnb_groups, a.gnb_silu = int(gnb.groups), int(gnb.silu)
+        nch = lib.query("vae_conv_gnb_chunks", C.byref(a))
+        if nch > 0:
+            ws = torch.empty((B, nch, Ci, 2), device=src.device, dtype=torch.float32)
+            a.gnb_ws = _p(ws)
+            out._gnb = (ws, nch, gnb.x.data_ptr())
+        else:
+            a.gnb_x = None
     _launch_igemm(a)
     if pool:
         pooled = torch.empty((B, H, W, Ci), device=src.device, dtype=torch.float32)
@@ -893,15 +919,19 @@ def gn_bwd(x: torch.Tensor, g: torch.Tensor, st: Stats, gamma: torch.Tensor, bet
         add = _like(add.contiguous(), x.dtype == torch.bfloat16)
     B, H, W, Cc = x.shape
     HW = H * W
-    nch = _gn_nchunk(B, HW, Cc)
     dev = x.device
-    ws = torch.empty((B, nch, Cc, 2), device=dev, dtype=torch.float32)
     coef = torch.empty((B, G, 2), device=dev, dtype=torch.float32)
     dx = torch.empty(x.shape, device=dev, dtype=torch.float32) if want32 else None
     dx16 = torch.empty(x.shape, device=dev, dtype=torch.bfloat16) if want16 else None
     s = _stream()
-    lib.call("vae_gn_bwd_partial", _p(x), _b16(x), _p(g), _p(st.mean), _p(st.rstd), _p(gamma), _p(beta), B, HW, Cc, G, nch,
-             int(silu), int(g16), _p(ws), s)
+    fused = getattr(g, "_gnb", None)  # the dgrad that produced g left the first pass's sums (conv_dgrad(gnb=...))
+    if fused is not None and fused[2] == x.data_ptr():
+        ws, nch = fused[0], fused[1]
+    else:
+        nch = _gn_nchunk(B, HW, Cc)
+        ws = torch.empty((B, nch, Cc, 2), device=dev, dtype=torch.float32)
+        lib.call("vae_gn_bwd_partial", _p(x), _b16(x), _p(g), _p(st.mean), _p(st.rstd), _p(gamma), _p(beta), B, HW, Cc, G, nch,
+                 int(silu), int(g16), _p(ws), s)
     lib.call("vae_gn_bwd_final", _p(ws), _p(st.rstd), _p(gamma), B, HW, Cc, G, nch, _p(dgamma), _p(dbeta), _p(coef), s)
     lib.call("vae_gn_bwd_apply", _p(x), _b16(x), _p(g), _p(st.mean), _p(st.rstd), _p(gamma), _p(beta), _p(coef), _p(add), B, HW,
              Cc, G, int(silu), int(g16), _p(dx), _p(dx16), s)
