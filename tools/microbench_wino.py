@@ -13,7 +13,7 @@ from vaehip import ops  # noqa: E402
 SHAPES = {"c128": (16, 256, 128, 128), "c256": (16, 128, 256, 256), "c512": (16, 64, 512, 512), "c512s": (16, 32, 512, 512)}
 
 
-def timeit(fn, n=5):
+def timeit(fn, n=40):  # (enough launches for the clock to settle)
     fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

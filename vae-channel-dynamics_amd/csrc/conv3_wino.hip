@@ -26,6 +26,7 @@
 // (tests/test_kernels_gpu.py), far inside the 1e-4 bar.  The epilogue also leaves the GroupNorm centred moments of the outputs
 // (one chunk per workgroup tile, as the direct kernels do); a tracked output stays on the direct kernel.
 #include "common.h"
+#include <type_traits>
 #include <algorithm>
 
 namespace {
@@ -209,12 +210,14 @@ __global__ __launch_bounds__(WNT, (NB == 4 ? 2 : 4)) void conv3_wino_kernel(vae_
 #pragma unroll
   for (int q = 0; q < NB; ++q) bvo[q] = (n0 + q * 32 + lr < p.N) ? (unsigned)(((n0 + q * 32 + lr) * 8 + lh * 4) * 4) : BUF_OOB;
   const unsigned bpos = (unsigned)p.N * 32u;  // bytes per position of the U image
-  auto load_b = [&](int step, f32x4 (&bq)[2 * NB]) {
-    if (step >= nsteps) return;  // (uniform; the registers are not used again)
-    const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(step * 16 + 2 * wave) * bpos);
-#pragma unroll
-    for (int i = 0; i < 2 * NB; ++i)
-      bq[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsU, bvo[i % NB], so + (i / NB) * bpos, 0));
+  // ONE register set: the fragment of (position pi, channel block nb) for step s+1 is requested right behind the four MFMAs
+  // that consume step s's (two sets -- 32 registers -- did not fit the 128-register budget of two workgroups per CU next to the
+  // accumulators and the staging role: 7 registers spilled).  Every step issues the same 2 NB requests; beyond the last chunk
+  // the last one is requested again and never used.
+  f32x4 bq[2 * NB];
+  auto load_b1 = [&](int step, int i) {
+    const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(min(step, nsteps - 1) * 16 + 2 * wave) * bpos);
+    bq[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsU, bvo[i % NB], so + (i / NB) * bpos, 0));
   };
 
   f32x16 acc[2][NB];
@@ -226,8 +229,8 @@ __global__ __launch_bounds__(WNT, (NB == 4 ? 2 : 4)) void conv3_wino_kernel(vae_
       for (int e = 0; e < 16; ++e) acc[pi][nb][e] = 0.f;
 
   // prologue: halo(0), halo(1) in LDS, V(0) from halo(0); halo(2) and the U fragments of step 0 in registers
-  f32x4 bq0[2 * NB], bq1[2 * NB];
-  load_b(0, bq0);
+#pragma unroll
+  for (int i = 0; i < 2 * NB; ++i) load_b1(0, i);
   {  // the three halo requests of the prologue go out together (one memory latency, not two)
     Halo h0 = rh, h1 = rh;
     load_halo_into(0, h0);
@@ -243,20 +246,29 @@ __global__ __launch_bounds__(WNT, (NB == 4 ? 2 : 4)) void conv3_wino_kernel(vae_
   // 0..3 (which own the V transform) stage first and multiply afterwards, waves 4..7 multiply first.  Step s: V(s+1) from
   // halo(s+1) [published by the previous barrier]; halo(s+2) -> the buffer halo(s) left; requests for the U fragments of step
   // s+1 (into the register set step s-1 used) and halo(s+3).  One barrier per step: it publishes V(s+1) and halo(s+2).
-  auto multiply = [&](const f32x4* a4, const f32x4 (&bq)[2 * NB]) {
+  auto multiply = [&](const f32x4* a4, int s) {  // step s; requests step s+1's fragments as it goes
 #pragma unroll
     for (int pi = 0; pi < 2; ++pi)
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb)
+      for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[pi][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[pi][e], bq[pi * NB + nb][e], acc[pi][nb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_b1(s + 1, pi * NB + nb);
+        __builtin_amdgcn_sched_barrier(0);
+      }
   };
   auto stage_next = [&](int s, int par) {
     if (s + 1 < nsteps) write_v(sH + (par ^ 1) * SHL, sV + (par ^ 1) * SV);  // V(s+1): nobody reads that buffer now
     store_halo(sH + par * SHL, s + 2);                                       // halo(s+2)
     load_halo(s + 3);
   };
-  auto step = [&](int s, int par, const f32x4 (&cur)[2 * NB], f32x4 (&nxt)[2 * NB]) {
+  // Waves 0..3 and 4..7 run SEPARATE copies of the loop (same number of barriers): inside one copy the order of the memory
+  // requests is fixed, so hipcc's wait counts are exact -- with both orders in one loop body it merged the two states at every
+  // join and put vmcnt(0) in front of the staging and at the loop head: each step then waited for the round trip of the
+  // requests it had just issued.
+  auto step = [&](int s, int par, auto first_c) {
+    constexpr bool STAGE_FIRST = decltype(first_c)::value;
     const float* cV = sV + par * SV;
     f32x4 a4[2];
     auto read_a = [&]() {
@@ -264,22 +276,20 @@ __global__ __launch_bounds__(WNT, (NB == 4 ? 2 : 4)) void conv3_wino_kernel(vae_
       for (int pi = 0; pi < 2; ++pi) a4[pi] = *reinterpret_cast<const f32x4*>(&cV[((2 * wave + pi) * NTL + lr) * WBK + 4 * lh]);
     };
     WSTAMP(0);
-    load_b(s + 1, nxt);
-    __builtin_amdgcn_sched_barrier(0);
     WSTAMP(1);
-    if (wave < 4) {  // uniform per wave
+    if (STAGE_FIRST) {
       stage_next(s, par);
       WSTAMP(2);
       read_a();
       __builtin_amdgcn_sched_barrier(0);
       WSTAMP(3);
-      multiply(a4, cur);
+      multiply(a4, s);
       __builtin_amdgcn_sched_barrier(0);
       WSTAMP(4);
     } else {
       read_a();
       WSTAMP(2);
-      multiply(a4, cur);
+      multiply(a4, s);
       __builtin_amdgcn_sched_barrier(0);
       WSTAMP(3);
       stage_next(s, par);
@@ -292,14 +302,16 @@ __global__ __launch_bounds__(WNT, (NB == 4 ? 2 : 4)) void conv3_wino_kernel(vae_
 #endif
   };
   WEDGE(1);
-  {
+  auto run = [&](auto first_c) {
     int s = 0;
     for (; s + 1 < nsteps; s += 2) {
-      step(s, 0, bq0, bq1);
-      step(s + 1, 1, bq1, bq0);
+      step(s, 0, first_c);
+      step(s + 1, 1, first_c);
     }
-    if (s < nsteps) step(s, 0, bq0, bq1);
-  }
+    if (s < nsteps) step(s, 0, first_c);
+  };
+  if (wave < 4) run(std::true_type{});  // uniform per wave
+  else run(std::false_type{});
 
   WEDGE(2);
 #if defined(VAE_WINO_TIMING) && VAE_WINO_TIMING >= 2
