@@ -14,7 +14,7 @@ from vaehip import ops  # noqa: E402
 SHAPES = {"u512": (16, 64, 512, 512), "u256": (16, 128, 256, 256), "u512s": (16, 32, 512, 512)}  # B, low-resolution side, Cin, Cout
 
 
-def timeit(fn, n=5):
+def timeit(fn, n=40):  # (enough launches for the clock to settle)
     fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -24,6 +24,7 @@
 // SIMD k % 4), so a workgroup loads the SIMDs 20 20 16 16 MFMAs per step and two co-resident workgroups 36 each.  (A first
 // version with one position per wave and 9 waves put three waves of every workgroup on SIMD 0: 0.46 of the matrix peak.)
 #include "common.h"
+#include <type_traits>
 #include <algorithm>
 
 namespace {
@@ -173,13 +174,14 @@ __global__ __launch_bounds__(UNT, 4) void conv3_upwino_kernel(vae_igemm_args p, 
   for (int q = 0; q < UNB; ++q) bvo[q] = (n0 + q * 32 + lr < p.N) ? (unsigned)(((n0 + q * 32 + lr) * 8 + lh * 4) * 4) : BUF_OOB;
   const unsigned bpos = (unsigned)p.N * 32u;  // bytes per position of the U image
   const unsigned bvx = extra ? bvo[xnb & 1] : BUF_OOB;  // the ninth position's block (waves without one request nothing)
-  auto load_b = [&](int step, f32x4 (&bq)[UNB + 1]) {
-    if (step >= nsteps) return;  // (uniform; the registers are not used again)
-    const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(step * NPOS + wave) * bpos);
-    const unsigned sx = __builtin_amdgcn_readfirstlane((unsigned)(step * NPOS + 8) * bpos);
-#pragma unroll
-    for (int i = 0; i < UNB; ++i) bq[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsU, bvo[i], so, 0));
-    bq[UNB] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsU, bvx, sx, 0));
+  // ONE register set, refilled behind the MFMAs that consume it (conv3_wino.hip); every step issues the same UNB + 1 requests
+  // in code every wave runs (beyond the last chunk the last one again, never used; waves without a ninth-position block request
+  // out of range)
+  f32x4 bq[UNB + 1];
+  auto load_b1 = [&](int step, int i) {
+    const int st = min(step, nsteps - 1);
+    const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(st * NPOS + (i < UNB ? wave : 8)) * bpos);
+    bq[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsU, i < UNB ? bvo[i < UNB ? i : 0] : bvx, so, 0));
   };
 
   f32x16 acc[UNB], accx;
@@ -191,8 +193,8 @@ __global__ __launch_bounds__(UNT, 4) void conv3_upwino_kernel(vae_igemm_args p, 
   for (int e = 0; e < 16; ++e) accx[e] = 0.f;
 
   // prologue: halo(0), halo(1) in LDS, V(0) from halo(0); halo(2) and the U fragments of step 0 in registers
-  f32x4 bq0[UNB + 1], bq1[UNB + 1];
-  load_b(0, bq0);
+#pragma unroll
+  for (int i = 0; i <= UNB; ++i) load_b1(0, i);
   {
     f32x4 h0, h1;
     load_halo_into(0, h0);
@@ -204,47 +206,56 @@ __global__ __launch_bounds__(UNT, 4) void conv3_upwino_kernel(vae_igemm_args p, 
   __syncthreads();
   write_v(sH, sV);
   __syncthreads();
-  auto multiply = [&](const float* cV, const f32x4 (&bq)[UNB + 1]) {
+  auto multiply = [&](const float* cV, int s) {  // step s; requests step s+1's fragments as it goes
     const f32x4 a4 = *reinterpret_cast<const f32x4*>(&cV[(wave * UTL + lr) * UBK + 4 * lh]);
     f32x4 ax = a4;
     if (extra) ax = *reinterpret_cast<const f32x4*>(&cV[(8 * UTL + lr) * UBK + 4 * lh]);
 #pragma unroll
-    for (int nb = 0; nb < UNB; ++nb)
+    for (int nb = 0; nb < UNB; ++nb) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], bq[nb][e], acc[nb], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_b1(s + 1, nb);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     if (extra) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) accx = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[e], bq[UNB][e], accx, 0, 0, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    load_b1(s + 1, UNB);
+    __builtin_amdgcn_sched_barrier(0);
   };
   auto stage_next = [&](int s, int par) {
     if (s + 1 < nsteps) write_v(sH + (par ^ 1) * USH, sV + (par ^ 1) * USV);  // V(s+1): nobody reads that buffer now
     store_halo_from(sH + par * USH, rh);                                       // halo(s+2)
     load_halo_into(s + 3, rh);
   };
-  auto step = [&](int s, int par, const f32x4 (&cur)[UNB + 1], f32x4 (&nxt)[UNB + 1]) {
+  // waves 0..3 (which own the V transform) stage first, waves 4..7 multiply first: two copies of the loop, so that the order of
+  // the memory requests is fixed inside each and hipcc's wait counts are exact (conv3_wino.hip)
+  auto step = [&](int s, int par, auto first_c) {
     const float* cV = sV + par * USV;
-    load_b(s + 1, nxt);
-    __builtin_amdgcn_sched_barrier(0);
-    if (wave < 4) {  // uniform per wave: the waves that own the V transform stage first, the others multiply first
+    if (decltype(first_c)::value) {
       stage_next(s, par);
       __builtin_amdgcn_sched_barrier(0);
-      multiply(cV, cur);
+      multiply(cV, s);
     } else {
-      multiply(cV, cur);
+      multiply(cV, s);
       __builtin_amdgcn_sched_barrier(0);
       stage_next(s, par);
     }
     __syncthreads();
   };
-  {
+  auto run = [&](auto first_c) {
     int s = 0;
     for (; s + 1 < nsteps; s += 2) {
-      step(s, 0, bq0, bq1);
-      step(s + 1, 1, bq1, bq0);
+      step(s, 0, first_c);
+      step(s + 1, 1, first_c);
     }
-    if (s < nsteps) step(s, 0, bq0, bq1);
-  }
+    if (s < nsteps) step(s, 0, first_c);
+  };
+  if (wave < 4) run(std::true_type{});  // uniform per wave
+  else run(std::false_type{});
 
   // ---- epilogue: per 32-channel block, M through LDS, then the output transform ----
   float* const sM = wsm;  // [9][32 tiles][UMLD], over the V / halo buffers (the last step's barrier has passed)
