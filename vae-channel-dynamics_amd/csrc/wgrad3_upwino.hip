@@ -30,7 +30,7 @@ constexpr int SXF = 3 * GCI * XSX;      // halo stage: [3 rows][32 ci][XSX]
 constexpr int SYF = 2 * GCO * XSY;      // dY stage:   [2 rows][128 co][XSY]
 constexpr int GSTAGE = SXF + SYF;       // 6272 floats (25088 B)
 
-__global__ __launch_bounds__(GNT, 4) void wgrad3_upwino_kernel(vae_wgrad_args p, int strips, int64_t nunits) {
+__global__ __launch_bounds__(GNT, 2) void wgrad3_upwino_kernel(vae_wgrad_args p, int strips, int64_t nunits) {
   __shared__ __attribute__((aligned(16))) float smem[2 * GSTAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;  // wave = position (pr, pc) 0..7; position 8: block `wave` on waves 0..3
