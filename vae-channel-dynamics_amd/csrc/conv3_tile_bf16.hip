@@ -320,6 +320,20 @@ __global__ __launch_bounds__(NT, 2) void conv3_tile_bf16_kernel(vae_igemm_args p
     const auto rsR = VAE_BUF_RSRC((p.res ? p.res : p.C) + (int64_t)cur.b * (g.Ho * cs) * (g.Wo * cs) * p.ldc, obytes);
     float tsum[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, gs1[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, gs2[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
     float gpv[2][2] = {{0.f, 0.f}, {0.f, 0.f}};  // statistics as shifted sums around the lane's first value
+    // the bias values of this lane's channels, loaded once per tile before the first store (per block each load sat behind the
+    // previous block's stores, and its wait -- vmcnt counts stores too -- waited for their acknowledgements: conv3_wide_bf16.hip)
+    float pbias[2][2];  // [channel block][channel of the lane pair / the lane's own channel]
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int col = cur.n0 + wn * 64 + ni * 32 + lr;
+      const bool cok = p.bias && col < p.N;
+      if (p.out_bf16) {  // uniform
+        pbias[ni][0] = cok ? p.bias[col & ~1] : 0.f;
+        pbias[ni][1] = cok ? p.bias[col | 1] : 0.f;
+      } else {
+        pbias[ni][0] = pbias[ni][1] = cok ? p.bias[col] : 0.f;
+      }
+    }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
       const int oy = cur.y0 + 2 * wm + mi;
@@ -334,7 +348,7 @@ __global__ __launch_bounds__(NT, 2) void conv3_tile_bf16_kernel(vae_igemm_args p
           const auto rsC16 = VAE_BUF_RSRC(reinterpret_cast<u16*>(p.C) + (int64_t)cur.b * (g.Ho * cs) * (g.Wo * cs) * p.ldc, ob16);
           const auto rsR16 = VAE_BUF_RSRC(reinterpret_cast<const u16*>(p.res ? p.res : p.C) + (int64_t)cur.b * (g.Ho * cs) * (g.Wo * cs) * p.ldc, ob16);
           const bool odd = lr & 1;
-          const float b0 = (p.bias && colok) ? p.bias[col & ~1] : 0.f, b1 = (p.bias && colok) ? p.bias[col | 1] : 0.f;
+          const float b0 = pbias[ni][0], b1 = pbias[ni][1];  // (rows beyond the image: the stores are out of range)
           unsigned o16[8], rr[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
@@ -366,7 +380,7 @@ __global__ __launch_bounds__(NT, 2) void conv3_tile_bf16_kernel(vae_igemm_args p
           }
           continue;
         }
-        const float bv = (p.bias && colok) ? p.bias[col] : 0.f;
+        const float bv = pbias[ni][0];
         unsigned off[16];
         float rv[16];
 #pragma unroll

@@ -336,6 +336,17 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
         }
       const unsigned pstep = (unsigned)(cs * p.ldc * 2);  // bytes per pixel step of the row grid
       auto off2 = [&](int r, int ni, int e) -> unsigned { return b2[r][ni] + (unsigned)(2 * ((e >> 1) & 1) + 8 * (e >> 2)) * pstep; };
+      // the bias of the lane pair's channels, both channel blocks: loaded ONCE per tile, before the first store.  (Loaded per
+      // 16-pixel block, each load sat behind the previous block's stores and its wait -- vmcnt counts stores too -- made every
+      // block wait for the write acknowledgements of the one before: 8 store round trips per tile, 10 of a 128-channel tile's 42
+      // thousand cycles, also without a bias: the wait stays when the load is branched around.)
+      float pb0[2], pb1[2];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int col = cur.n0 + wn * 64 + ni * 32 + lr;
+        pb0[ni] = (p.bias && col < p.N) ? p.bias[col & ~1] : 0.f;
+        pb1[ni] = (p.bias && col < p.N) ? p.bias[col | 1] : 0.f;
+      }
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         unsigned rr[4][8];
@@ -352,8 +363,7 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int r = 2 * hf + (q >> 1), ni = q & 1;
-          const int col = cur.n0 + wn * 64 + ni * 32 + lr;
-          const float b0 = (p.bias && col < p.N) ? p.bias[col & ~1] : 0.f, b1 = (p.bias && col < p.N) ? p.bias[col | 1] : 0.f;
+          const float b0 = pb0[ni], b1 = pb1[ni];
           gs1[r][ni] = gs2[r][ni] = gpv[r][ni] = 0.f;
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
@@ -385,6 +395,12 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
           return (col < p.N && oy < g.Ho && ox < g.Wo) ? (unsigned)((((oy * cs + p.c_oy) * (g.Wo * cs) + ox * cs + p.c_ox) * p.ldc + col) * 4) : BUF_OOB;
         return (col < p.N && oy < g.Ho && ox < g.Wo) ? (unsigned)(((oy * g.Wo + ox) * p.ldc + col) * 4) : BUF_OOB;
       };
+      float pbv[2];  // (once per tile, before the first store: see the bf16 branch)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int col = cur.n0 + wn * 64 + ni * 32 + lr;
+        pbv[ni] = (p.bias && col < p.N) ? p.bias[col] : 0.f;
+      }
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         float rv[4][16];
@@ -402,8 +418,7 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int r = 2 * hf + (q >> 1), ni = q & 1;
-          const int col = cur.n0 + wn * 64 + ni * 32 + lr;
-          const float bv = (p.bias && col < p.N) ? p.bias[col] : 0.f;
+          const float bv = pbv[ni];
           gs1[r][ni] = gs2[r][ni] = gpv[r][ni] = 0.f;
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
