@@ -121,3 +121,44 @@ def test_accumulated_update_exchange_world2():
     want2 = (12 / 3 + 120 / 3) / 2
     for s in (s0, s1):
         assert s[0] == pytest.approx((want1,) * 4) and s[1] == pytest.approx((want2,) * 4)
+
+
+def _agree_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import train
+        good = {"pixel_values": torch.zeros(2, 3, 8, 8)}
+        # rank 1's second batch fails to decode (None), rank 0's fourth has no samples: both ranks must skip both
+        batches = [good, None if rank == 1 else good, good, {"pixel_values": torch.zeros(0, 3, 8, 8)} if rank == 0 else good, good]
+        seen = [(ok, last, b is not None and b["pixel_values"].shape[0] > 0) for b, ok, last in train.agreed_batches(batches, world)]
+        q.put((rank, seen, list(train.agreed_batches([], world))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_batch_validity_is_agreed_one_step_ahead_world2():
+    """train.py's control plane: a batch is trained only when it is valid on EVERY rank (the reference crashes on a None batch,
+    data_utils.py:215; with one rank skipping alone the gradient exchange would hang); the agreement runs as an asynchronous
+    gloo all-reduce started one batch ahead"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_agree_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, seen, empty in out:
+        assert [s[0] for s in seen] == [True, False, True, False, True], (rank, seen)   # the same decisions on both ranks
+        assert [s[1] for s in seen] == [False, False, False, False, True] and empty == []
+    assert {r: [s[2] for s in seen] for r, seen, _ in out} == {0: [True, True, True, False, True], 1: [True, False, True, True, True]}
+
+
+def test_batch_agreement_without_a_process_group():
+    import train
+    good = {"pixel_values": torch.zeros(1, 3, 8, 8)}
+    assert [(ok, last) for _, ok, last in train.agreed_batches([good, None, good], 1)] == [(True, False), (False, False), (True, True)]

@@ -136,6 +136,43 @@ def all_ranks_ok(ok: bool, world: int) -> bool:
     return bool(flag.item())
 
 
+def agreed_batches(loader, world: int):
+    """yields (batch, every rank's batch is valid, last of the pass).  The agreement on batch k+1 (all_ranks_ok's int32 MIN
+    all-reduce on the gloo control group) is STARTED when the look-ahead of `with_last` fetches that batch and awaited one step
+    later, so it runs behind batch k's host work instead of in front of every step (blocking: 0.36 ms per call at 2 ranks,
+    0.9 ms at 8 on an 8-core host, tools/ctrl_allreduce_cost.py).  Every rank issues the same collectives in the same order."""
+    global _CTRL_GROUP
+
+    def start(b):
+        ok = valid_batch(b)
+        if world <= 1:
+            return ok, None, None
+        global _CTRL_GROUP
+        if _CTRL_GROUP is None:
+            _CTRL_GROUP = dist.new_group(backend="gloo")
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        return ok, flag, dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=_CTRL_GROUP, async_op=True)
+
+    def finish(tok):
+        ok, flag, work = tok
+        if work is None:
+            return ok
+        work.wait()
+        return bool(flag.item())
+
+    it = iter(loader)
+    try:
+        cur = next(it)
+    except StopIteration:
+        return
+    tok = start(cur)
+    for nxt in it:
+        ntok = start(nxt)
+        yield cur, finish(tok), False
+        cur, tok = nxt, ntok
+    yield cur, finish(tok), True
+
+
 def valid_batch(batch) -> bool:
     pv = batch.get("pixel_values") if batch else None  # guards the reference's None-batch crash (data_utils.py:215)
     return pv is not None and pv.ndim == 4 and pv.shape[0] > 0
@@ -162,8 +199,8 @@ def run_validation(trainer: HipTrainer, val_dataloader, kl_weight: float, global
     logger.info(f"--- Running Validation for Global Step: {global_step} ---")
     trainer.wrapper.eval()
     sums = torch.zeros(3, device=device, dtype=torch.float64)  # rec_sum, kl_sum, samples
-    for batch in val_dataloader:
-        if not all_ranks_ok(valid_batch(batch), world):  # every rank skips together (tracker buffers stay aligned)
+    for batch, ok_everywhere, _ in agreed_batches(val_dataloader, world):
+        if not ok_everywhere:  # every rank skips together (tracker buffers stay aligned)
             logger.warning("Validation: Invalid batch data, skipping.")
             continue
         pv = batch["pixel_values"]
@@ -313,8 +350,8 @@ def main():
         epoch_sums = torch.zeros(3, device=device, dtype=torch.float64)  # mse, kl, total (this rank)
         steps_in_epoch = 0
         sc = torch.zeros(3, device=device)
-        for batch, last_batch in with_last(train_dataloader):
-            if not all_ranks_ok(valid_batch(batch), world):  # all ranks skip the batch, or none does
+        for batch, ok_everywhere, last_batch in agreed_batches(train_dataloader, world):
+            if not ok_everywhere:  # all ranks skip the batch, or none does
                 if last_batch and trainer.pending_micro_batches:
                     trainer.flush()  # the pass ends on a skipped batch: update with what has accumulated
                 else:
