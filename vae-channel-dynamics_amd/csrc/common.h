@@ -68,6 +68,38 @@ __device__ __forceinline__ bool src_pixel(const vae_conv_geom& g, int y, int x, 
   }
 }
 
+// The same mapping without a branch on g.mode: the four geometries as one affine form t = y a + kh b + c with a range check,
+// a parity mask and a shift, from wave-uniform constants built once per kernel.  (The flat kernels call the mapping for every
+// operand load of every step; with the mode switch inside, each call compiled into ~60 scalar instructions and ten branches:
+// address generation, not the matrix pipe, bounded the bf16 flat kernels -- 135-300 TFLOP/s.)
+struct SrcMap {
+  int a, b, cy, cx, pm, sh, Hs, Ws;
+  unsigned limy, limx;
+};
+__device__ __forceinline__ SrcMap make_srcmap(const vae_conv_geom& g) {
+  // (selects, not an if / else-if chain over g.mode: hipcc 7.2 compiled the chain into a structurised flow whose DGRAD arm
+  // came out with the UP2X constants -- tools/srcmap_check.hip compares both mappings on the device)
+  const bool fwd = g.mode == VAE_MODE_FWD, up = g.mode == VAE_MODE_UP2X, s2 = g.mode == VAE_MODE_DGRAD_S2;
+  const bool dg = !(fwd || up || s2);
+  SrcMap m;
+  m.Hs = g.Hs; m.Ws = g.Ws;
+  m.a = fwd ? g.stride : 1;
+  m.b = (fwd || up) ? 1 : -1;
+  m.cy = fwd ? -g.pad_t : (up ? -1 : (s2 ? 0 : g.pad_t));
+  m.cx = fwd ? -g.pad_l : (up ? -1 : (s2 ? 0 : g.pad_l));
+  m.pm = (dg && g.stride == 2) ? 1 : 0;
+  m.sh = (up || s2) ? 1 : m.pm;
+  m.limy = up ? 2u * (unsigned)g.Hs : 0x7fffffffu;  // (0x7fffffff: rejects negative t)
+  m.limx = up ? 2u * (unsigned)g.Ws : 0x7fffffffu;
+  return m;
+}
+__device__ __forceinline__ bool src_pixel(const SrcMap& m, int y, int x, int kh, int kw, int& sy, int& sx) {
+  const int ty = y * m.a + kh * m.b + m.cy, tx = x * m.a + kw * m.b + m.cx;
+  sy = ty >> m.sh;
+  sx = tx >> m.sh;
+  return ((unsigned)ty < m.limy) & ((unsigned)tx < m.limx) & (((ty | tx) & m.pm) == 0) & ((unsigned)sy < (unsigned)m.Hs) & ((unsigned)sx < (unsigned)m.Ws);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -163,6 +195,18 @@ constexpr size_t BUF_MAX = 0xFFFFFFF0u;  // bytes one descriptor can cover
 #define VAE_BUF_RSRC(ptr, bytes) \
   __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(static_cast<const void*>(ptr)), 0, (unsigned)(bytes), 0x00020000)
 #define VAE_BUF_LOAD4(rsrc, off) __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128((rsrc), (off), 0, 0))
+// `ok ? <address arithmetic> : BUF_OOB` as the offset of a load: hipcc turns the select into a branch around the arithmetic
+// and duplicates the LOAD into both arms; the arm that computes the address then waits (vmcnt(0)) for the other arm's
+// destination registers, so every load of a pipeline step sits behind the previous one's round trip (the flat kernels' loops,
+// round 3).  With the computed offset made opaque first the select stays one v_cndmask and the loads go out back to back.
+__device__ __forceinline__ unsigned oob_unless(bool ok, unsigned off) {
+  asm volatile("" : "+v"(off));
+  return ok ? off : BUF_OOB;
+}
+__device__ __forceinline__ int neg_unless(bool ok, int idx) {  // the same for element indices (-1 = do not request)
+  asm volatile("" : "+v"(idx));
+  return ok ? idx : -1;
+}
 
 // LDS-table variant: no bounds branches (table entries beyond the valid columns are zero-filled)
 template <int XF>

@@ -100,6 +100,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_rows_kernel(vae_igemm_args
   const int m0 = tm * BM, n0 = tn * BN;
   const int z = blockIdx.z;
   const vae_conv_geom g = p.g;
+  const SrcMap smap = make_srcmap(g);
   const float* __restrict__ A = p.A + (int64_t)z * p.sAb;
   const float* __restrict__ W = p.W + (int64_t)z * p.sWb;
   const int hw = g.Ho * g.Wo;
@@ -196,9 +197,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_rows_kernel(vae_igemm_args
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       int sy = 0, sx = 0;
-      const bool ok = src_pixel(g, ry[i], rx[i], kh, kw, sy, sx) && (rb[i] >= 0);
+      const bool ok = src_pixel(smap, ry[i], rx[i], kh, kw, sy, sx) && (rb[i] >= 0);
       if (VEC) {
-        ra[i] = VAE_BUF_LOAD4(rsA, (ok && c < p.K) ? ((unsigned)(((rb[i] - b_base) * g.Hs + sy) * g.Ws + sx) * (unsigned)g.Cs + (unsigned)c) * 4u : BUF_OOB);
+        ra[i] = VAE_BUF_LOAD4(rsA, oob_unless(ok && c < p.K, ((unsigned)(((rb[i] - b_base) * g.Hs + sy) * g.Ws + sx) * (unsigned)g.Cs + (unsigned)c) * 4u));
       } else {
         ra[i] = load4s(A + (((int64_t)rb[i] * g.Hs + sy) * g.Ws + sx) * g.Cs + c, ok, c, p.K);
       }
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_rows_kernel(vae_igemm_args
 #pragma unroll
       for (int i = 0; i < BR; ++i) {
         const int n = n0 + r0 + RP * i;
-        if (VEC) rbw[i] = VAE_BUF_LOAD4(rsW, (n < p.N && c < p.K) ? ((unsigned)n * (unsigned)p.sn + (unsigned)tap * (unsigned)p.st + (unsigned)c) * 4u : BUF_OOB);
+        if (VEC) rbw[i] = VAE_BUF_LOAD4(rsW, oob_unless(n < p.N && c < p.K, ((unsigned)n * (unsigned)p.sn + (unsigned)tap * (unsigned)p.st + (unsigned)c) * 4u));
         else rbw[i] = load4s(W + (int64_t)n * p.sn + (int64_t)tap * p.st + c, n < p.N, c, p.K);
       }
     } else {
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_rows_kernel(vae_igemm_args
       for (int i = 0; i < BR; ++i) {
         const int k = c0 + kq + KR * i;
         const int n = n0 + n4 * 4;
-        if (VEC) rbw[i] = VAE_BUF_LOAD4(rsW, (k < p.K && n < p.N) ? ((unsigned)k * (unsigned)p.sk + (unsigned)tap * (unsigned)p.st + (unsigned)n) * 4u : BUF_OOB);
+        if (VEC) rbw[i] = VAE_BUF_LOAD4(rsW, oob_unless(k < p.K && n < p.N, ((unsigned)k * (unsigned)p.sk + (unsigned)tap * (unsigned)p.st + (unsigned)n) * 4u));
         else rbw[i] = load4s(W + (int64_t)k * p.sk + (int64_t)tap * p.st + n, k < p.K, n, p.N);
       }
     }
@@ -389,6 +390,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(vae_wgrad_args p) {
   const int tap = blockIdx.y / p.nsplit, split = blockIdx.y % p.nsplit;
   const int z = blockIdx.z;
   const vae_conv_geom g = p.g;
+  const SrcMap smap = make_srcmap(g);
   const int kh = (g.taps == 9) ? tap / 3 : 0, kw = (g.taps == 9) ? tap - kh * 3 : 0;
   const float* __restrict__ dY = p.dY + (int64_t)z * p.sYb;
   const float* __restrict__ X = p.X + (int64_t)z * p.sXb;
@@ -441,7 +443,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(vae_wgrad_args p) {
     for (int i = 0; i < AI; ++i) {
       const int pix = pb + akq + AKR * i;
       const int c = m0 + a4 * 4;
-      if (VEC) ra[i] = VAE_BUF_LOAD4(rsY, (pix < pend && c < p.M) ? ((unsigned)(pix - pbeg) * (unsigned)p.ldy + (unsigned)c) * 4u : BUF_OOB);
+      if (VEC) ra[i] = VAE_BUF_LOAD4(rsY, oob_unless(pix < pend && c < p.M, ((unsigned)(pix - pbeg) * (unsigned)p.ldy + (unsigned)c) * 4u));
       else ra[i] = load4s(dY + (int64_t)pix * p.ldy + c, pix < pend, c, p.M);
     }
 #pragma unroll
@@ -451,8 +453,8 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(vae_wgrad_args p) {
       const int b = pix / hw, rem = pix - b * hw;
       const int y = rem / g.Wo, x = rem - y * g.Wo;
       int sy = 0, sx = 0;
-      const bool ok = src_pixel(g, y, x, kh, kw, sy, sx) && (pix < pend);
-      if (VEC) rx[i] = VAE_BUF_LOAD4(rsX, (ok && c < p.N) ? ((unsigned)(((b - b_lo) * g.Hs + sy) * g.Ws + sx) * (unsigned)g.Cs + (unsigned)c) * 4u : BUF_OOB);
+      const bool ok = src_pixel(smap, y, x, kh, kw, sy, sx) && (pix < pend);
+      if (VEC) rx[i] = VAE_BUF_LOAD4(rsX, oob_unless(ok && c < p.N, ((unsigned)(((b - b_lo) * g.Hs + sy) * g.Ws + sx) * (unsigned)g.Cs + (unsigned)c) * 4u));
       else rx[i] = load4s(X + (((int64_t)b * g.Hs + sy) * g.Ws + sx) * g.Cs + c, ok, c, p.N);
       xb[i] = ok ? b : -1;
     }

@@ -38,6 +38,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_rows_bf16_kernel(vae_igemm
   const int m0 = tm * BM, n0 = tn * BN;
   const int z = blockIdx.z;
   const vae_conv_geom g = p.g;
+  const SrcMap smap = make_srcmap(g);
   const bool abf = p.a_bf16 != 0, cbf = p.out_bf16 != 0, rbf = p.res_bf16 != 0;  // storage of A / C / res (uniform)
   const unsigned esA = abf ? 2u : 4u;
   const char* __restrict__ A = reinterpret_cast<const char*>(p.A) + (int64_t)z * p.sAb * esA;
@@ -131,15 +132,15 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_rows_bf16_kernel(vae_igemm
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       int sy = 0, sx = 0;
-      const bool ok = src_pixel(g, ry[i], rx[i], kh, kw, sy, sx) && (rb[i] >= 0);
-      ra[i] = buf_load4_raw(rsA, esA, (ok && c < p.K) ? (((rb[i] - b_base) * g.Hs + sy) * g.Ws + sx) * g.Cs + c : -1);
+      const bool ok = src_pixel(smap, ry[i], rx[i], kh, kw, sy, sx) && (rb[i] >= 0);
+      ra[i] = buf_load4_raw(rsA, esA, neg_unless(ok && c < p.K, (((rb[i] - b_base) * g.Hs + sy) * g.Ws + sx) * g.Cs + c));
       a_b[i] = ok ? rb[i] : -1;
     }
     if (!BKM) {
 #pragma unroll
       for (int i = 0; i < BR; ++i) {
         const int n = n0 + r0 + RP * i;
-        rw[i] = VAE_BUF_LOAD4(rsW, (n < p.N && c < p.K) ? ((unsigned)n * (unsigned)p.sn + (unsigned)tap * (unsigned)p.st + (unsigned)c) * 4u : BUF_OOB);
+        rw[i] = VAE_BUF_LOAD4(rsW, oob_unless(n < p.N && c < p.K, ((unsigned)n * (unsigned)p.sn + (unsigned)tap * (unsigned)p.st + (unsigned)c) * 4u));
       }
     } else {
       constexpr int NQ = BN / 4, KR = NT / NQ;
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_rows_bf16_kernel(vae_igemm
       for (int i = 0; i < BR; ++i) {
         const int k = c0 + kq + KR * i;
         const int n = n0 + n4 * 4;
-        rw[i] = VAE_BUF_LOAD4(rsW, (k < p.K && n < p.N) ? ((unsigned)k * (unsigned)p.sk + (unsigned)tap * (unsigned)p.st + (unsigned)n) * 4u : BUF_OOB);
+        rw[i] = VAE_BUF_LOAD4(rsW, oob_unless(k < p.K && n < p.N, ((unsigned)k * (unsigned)p.sk + (unsigned)tap * (unsigned)p.st + (unsigned)n) * 4u));
       }
     }
   };
@@ -344,6 +345,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_bf16_kernel(vae_wgrad_args
   const int tap = blockIdx.y / p.nsplit, split = blockIdx.y % p.nsplit;
   const int z = blockIdx.z;
   const vae_conv_geom g = p.g;
+  const SrcMap smap = make_srcmap(g);
   const int kh = (g.taps == 9) ? tap / 3 : 0, kw = (g.taps == 9) ? tap - kh * 3 : 0;
   const bool ybf = p.y_bf16 != 0, xbf = p.x_bf16 != 0;  // storage of dY / X (uniform)
   const unsigned esY = ybf ? 2u : 4u, esX = xbf ? 2u : 4u;
@@ -396,7 +398,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_bf16_kernel(vae_wgrad_args
     for (int i = 0; i < AI; ++i) {
       const int pix = pb + akq + AKR * i;
       const int c = m0 + a4 * 4;
-      ra[i] = buf_load4_raw(rsY, esY, (pix < pend && c < p.M) ? (pix - pbeg) * p.ldy + c : -1);
+      ra[i] = buf_load4_raw(rsY, esY, neg_unless(pix < pend && c < p.M, (pix - pbeg) * p.ldy + c));
     }
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
@@ -405,8 +407,8 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_bf16_kernel(vae_wgrad_args
       const int b = pix / hw, rem = pix - b * hw;
       const int y = rem / g.Wo, x = rem - y * g.Wo;
       int sy = 0, sx = 0;
-      const bool ok = src_pixel(g, y, x, kh, kw, sy, sx) && (pix < pend);
-      rx[i] = buf_load4_raw(rsX, esX, (ok && c < p.N) ? (((b - b_lo) * g.Hs + sy) * g.Ws + sx) * g.Cs + c : -1);
+      const bool ok = src_pixel(smap, y, x, kh, kw, sy, sx) && (pix < pend);
+      rx[i] = buf_load4_raw(rsX, esX, neg_unless(ok && c < p.N, (((b - b_lo) * g.Hs + sy) * g.Ws + sx) * g.Cs + c));
       xb[i] = ok ? b : -1;
     }
   };
