@@ -42,9 +42,9 @@ for nm in (sys.argv[1:] or list(SHAPES)):
             continue
         sa, sb = a[1:-1], b[1:-1]  # steady state: without the first and the last step
         per = (a[-1, 5] - a[0, 0]) / nst
-        print(f"  wg {wg}: step {per:7.0f} ticks | wave 0: loads {np.mean(sa[:,1]-sa[:,0]):5.0f} stage {np.mean(sa[:,2]-sa[:,1]):5.0f} A-wait {np.mean(sa[:,3]-sa[:,2]):5.0f} "
-              f"mfma-issue {np.mean(sa[:,4]-sa[:,3]):5.0f} barrier {np.mean(sa[:,5]-sa[:,4]):5.0f} | wave 4: loads {np.mean(sb[:,1]-sb[:,0]):5.0f} A-wait {np.mean(sb[:,2]-sb[:,1]):5.0f} "
-              f"mfma-issue {np.mean(sb[:,3]-sb[:,2]):5.0f} stage {np.mean(sb[:,4]-sb[:,3]):5.0f} barrier {np.mean(sb[:,5]-sb[:,4]):5.0f}", flush=True)
+        print(f"  wg {wg}: step {per:7.0f} ticks | wave 0: stage {np.mean(sa[:,2]-sa[:,1]):5.0f} A-wait {np.mean(sa[:,3]-sa[:,2]):5.0f} mfma-issue {np.mean(sa[:,4]-sa[:,3]):5.0f} "
+              f"barrier {np.mean(sa[:,5]-sa[:,4]):5.0f} | wave 4: A-wait {np.mean(sb[:,2]-sb[:,1]):5.0f} mfma-issue {np.mean(sb[:,3]-sb[:,2]):5.0f} "
+              f"stage {np.mean(sb[:,4]-sb[:,3]):5.0f} barrier {np.mean(sb[:,5]-sb[:,4]):5.0f}", flush=True)
     e = stamps[8 * 2 * 64 * 6:8 * 2 * 64 * 6 + 8 * 2 * 10].cpu().numpy().reshape(8, 2, 10).astype("float64")
     for wg in range(8):
         v = e[wg, 0]
