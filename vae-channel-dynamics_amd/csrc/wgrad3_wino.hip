@@ -181,7 +181,6 @@ __global__ __launch_bounds__(GNT, 1) void wgrad3_wino_kernel(vae_wgrad_args p, i
     constexpr bool two = wic == 1 || wic == 2;  // D' row i combines both dY rows
     constexpr bool vplus = wic == 1;            // sign of the second row in the combinations (V: B^T row i, D': G' row i)
     auto step = [&](int k, const Stg& cur, Stg& nxt) {  // cur: unit k+1 (requested during step k-1); nxt receives unit k+2
-      load_unit(k + 2, nxt);
       const float* cx = smem + (k & 1) * GSTAGE;
       const float* cy = cx + SXF;
       float* nst = smem + ((k + 1) & 1) * GSTAGE;
@@ -248,6 +247,11 @@ __global__ __launch_bounds__(GNT, 1) void wgrad3_wino_kernel(vae_wgrad_args p, i
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb) {
         __builtin_amdgcn_sched_barrier(0);
+        if (nb == 1) {  // the requests for unit k+2 (index counters + 4 loads) behind the first block's MFMAs, not in front of the
+          // step, where both waves of a SIMD build operands and the matrix pipe has nothing to do (2.1-2.7 % of the kernel)
+          load_unit(k + 2, nxt);
+          __builtin_amdgcn_sched_barrier(0);
+        }
         if (nb < 3) build_b(rd, bb[(nb + 1) & 1]);  // block nb+1's operands, during the first half of this block's MFMAs
         if (nb < 2) read_d(nb + 2, rd);             // block nb+2's rows into the same registers, during the second half
 #pragma unroll
