@@ -252,6 +252,10 @@ __global__ __launch_bounds__(GNT, 1) void wgrad3_wino_kernel(vae_wgrad_args p, i
           load_unit(k + 2, nxt);
           __builtin_amdgcn_sched_barrier(0);
         }
+        if (nb == 3 && wave >= 4) {  // (waves 4..7: the LDS stores of unit k+1 behind the third block's MFMAs, not between the last MFMA and the barrier)
+          store_unit(nst, cur);
+          __builtin_amdgcn_sched_barrier(0);
+        }
         if (nb < 3) build_b(rd, bb[(nb + 1) & 1]);  // block nb+1's operands, during the first half of this block's MFMAs
         if (nb < 2) read_d(nb + 2, rd);             // block nb+2's rows into the same registers, during the second half
 #pragma unroll
@@ -267,7 +271,6 @@ __global__ __launch_bounds__(GNT, 1) void wgrad3_wino_kernel(vae_wgrad_args p, i
         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (wave >= 4) store_unit(nst, cur);
       __syncthreads();
     };
     int k = 0;
