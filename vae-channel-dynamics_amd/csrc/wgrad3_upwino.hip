@@ -64,13 +64,14 @@ __global__ __launch_bounds__(GNT, 2) void wgrad3_upwino_kernel(vae_wgrad_args p,
   const int xq = tid & 7, xc = (tid >> 3) % 10, xr = tid / 80;
   const auto rsX = VAE_BUF_RSRC(p.X, (size_t)g.B * g.Hs * g.Ws * g.Cs * 4u);
   const auto rsY = VAE_BUF_RSRC(p.dY, (size_t)g.B * g.Ho * g.Wo * p.ldy * 4u);
-  // ONE set of staging registers (the 128-VGPR budget of two workgroups per CU): unit k+1 is requested at the start of step k
-  // and stored at its end, behind the step's MFMAs
+  // TWO sets of staging registers (the kernel runs at a 256-register budget): unit k+2 is requested during step k, behind its
+  // first block's MFMAs, and stored at the end of step k+1 -- two steps (~3 us) of lead; with one set requested at the start
+  // of a step and stored at its end the store sat on the HBM round trip
   struct Stg {
     f32x4 rx, ry[2];
   };
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-  Stg s0{z4, {z4, z4}};
+  Stg s0{z4, {z4, z4}}, s1{z4, {z4, z4}};
   f32x4 bsum = z4;
   // the unit the next load_unit call requests (calls go through ubeg, ubeg+1, ...: counters instead of divisions per step)
   int ub = (int)(ubeg / upi), urow = (int)((ubeg - (int64_t)ub * upi) / strips), ustrip = (int)((ubeg - (int64_t)ub * upi) % strips);
@@ -117,6 +118,7 @@ __global__ __launch_bounds__(GNT, 2) void wgrad3_upwino_kernel(vae_wgrad_args p,
 
   load_unit(0, s0);
   store_unit(smem, s0);
+  load_unit(1, s1);
   __syncthreads();
 
   // operand builders for position (pr, pc).  V fragment: lane (ci = lr, half lh) takes tiles 4 lh + e: halo columns 4 lh .. 4 lh + 5
@@ -167,8 +169,7 @@ __global__ __launch_bounds__(GNT, 2) void wgrad3_upwino_kernel(vae_wgrad_args p,
   // The loop body is instantiated per position: straight-line code, no per-step branches.
   auto run = [&](auto PR, auto PC, auto EXTRA) {
     constexpr bool extra = decltype(EXTRA)::value;  // this wave also owns block `wave` of position 8 = (2, 2)
-    for (int k = 0; k < nu; ++k) {
-      load_unit(k + 1, s0);  // (s0's previous contents were stored at the end of step k-1)
+    auto step = [&](int k, const Stg& cur, Stg& nxt) {  // cur: unit k+1 (requested during step k-1); nxt receives unit k+2
       const float* cx = smem + (k & 1) * GSTAGE;
       const float* cy = cx + SXF;
       float* nst = smem + ((k + 1) & 1) * GSTAGE;
@@ -178,6 +179,10 @@ __global__ __launch_bounds__(GNT, 2) void wgrad3_upwino_kernel(vae_wgrad_args p,
 #pragma unroll
       for (int nb = 0; nb < GNB; ++nb) {
         __builtin_amdgcn_sched_barrier(0);
+        if (nb == 1) {  // the requests for unit k+2 (index counters + 3 loads) behind the first block's MFMAs
+          load_unit(k + 2, nxt);
+          __builtin_amdgcn_sched_barrier(0);
+        }
         if (nb + 1 < GNB) build_b(PR, PC, cy, nb + 1, bb[(nb + 1) & 1]);  // the next block's operands, while this block's MFMAs issue
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], bb[nb & 1][e], acc[nb], 0, 0, 0);
@@ -190,9 +195,15 @@ __global__ __launch_bounds__(GNT, 2) void wgrad3_upwino_kernel(vae_wgrad_args p,
 #pragma unroll
         for (int e = 0; e < 4; ++e) accx = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[e], bx[e], accx, 0, 0, 0);
       }
-      store_unit(nst, s0);
+      store_unit(nst, cur);
       __syncthreads();
+    };
+    int k = 0;
+    for (; k + 1 < nu; k += 2) {
+      step(k, s1, s0);
+      step(k + 1, s0, s1);
     }
+    if (k < nu) step(k, s1, s0);
   };
   {
     using I0 = std::integral_constant<int, 0>;
