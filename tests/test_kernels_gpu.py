@@ -8,6 +8,8 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 pytestmark = pytest.mark.gpu
 
 
@@ -1026,3 +1028,19 @@ def test_upsampler_winograd_wgrad(cuda, B, H, W, Ci, Co):
     g2, _ = run()  # deterministic
     assert torch.equal(g2, gw)
 
+
+
+def test_flat_kernels_source_pixel_mapping_on_the_device(cuda, tmp_path):
+    """common.h SrcMap (one branch-free affine form for the four geometries, what the flat kernels call per operand load) against
+    the mode-switch form, ON THE DEVICE: a first version of its builder compiled correctly for the host and wrongly for gfx950
+    (hipcc 7.2: the DGRAD arm came out with the UP2X constants), which only a device comparison shows"""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "srcmap_check")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "srcmap_check.hip"), "-o", exe],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("mode")]
+    assert out.returncode == 0 and len(lines) == 11 and all(ln.endswith("bad 0") for ln in lines), out.stdout + out.stderr
