@@ -117,6 +117,38 @@ def test_conv_forward_and_dgrad_with_bf16_storage(act16, kind, B, H, W, Ci, Co, 
     assert _rel(gw[0].cpu(), wg.grad) < 3e-5
 
 
+@pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 128, 128, 256, 128), (2, 128, 128, 128, 256), (3, 128, 96, 512, 256), (8, 64, 64, 256, 512)])
+def test_streaming_1x1_convolution_with_resident_weights(act16, B, H, W, Ci, Co):
+    """conv1_bf16.hip (the shortcut convolutions at full size: weights resident in LDS, A straight into MFMA fragments) against
+    the flat kernel on the same bf16 tensors and against torch on the rounded operands, forward and dgrad"""
+    from vaehip import ops
+    gen = torch.Generator().manual_seed(11 + Ci + Co + H)
+    x16 = _nhwc(torch.randn(B, Ci, H, W, generator=gen) * 1.2 + 0.1).bfloat16()
+    w = torch.randn(Co, Ci, 1, 1, generator=gen) / math.sqrt(Ci)
+    wd = act16(_to_dev_ohwi(w))
+    bias = torch.randn(Co, generator=gen).cuda()
+    dy16 = torch.randn(B, H, W, Co, generator=gen).cuda().bfloat16()
+    prof = ops.PROFILER = ops.LaunchProfiler()
+    try:
+        y = ops.conv_fwd(x16, wd, bias, "c1")
+        d = ops.conv_dgrad(dy16, wd, "c1", (H, W))
+    finally:
+        ops.PROFILER = None
+    dgk = f"conv1_bf16_kernel<true,{Co // 16}>" if Co <= 256 else "igemm_rows_bf16_kernel<128,128,4,2,true,0>"  # (a 512-row [k][n] slice does not fit LDS)
+    assert _names(prof) == [f"conv1_bf16_kernel<false,{Ci // 16}>", dgk], _names(prof)
+    assert y.dtype == torch.bfloat16 and d.dtype == torch.bfloat16
+    with ops.option("flat_conv"):
+        yf = ops.conv_fwd(x16, wd, bias, "c1")
+        df = ops.conv_dgrad(dy16, wd, "c1", (H, W))
+    assert _rel(y.float(), yf.float()) < 4e-3 and _rel(d.float(), df.float()) < 4e-3  # at most one bf16 ulp apart
+    xr, wr = x16.float().cpu().permute(0, 3, 1, 2), w.bfloat16().float()
+    assert _rel(y.float().cpu().permute(0, 3, 1, 2), F.conv2d(xr, wr, bias.cpu())) < 6e-3
+    xg = xr.clone().requires_grad_(True)
+    (gx,) = torch.autograd.grad(F.conv2d(xg, wr), xg, dy16.float().cpu().permute(0, 3, 1, 2))
+    assert _rel(d.float().cpu().permute(0, 3, 1, 2), gx) < 6e-3
+    assert torch.equal(ops.conv_fwd(x16, wd, bias, "c1"), y)  # deterministic
+
+
 @pytest.mark.parametrize("C,H,W,silu", [(128, 16, 16, True), (512, 6, 10, False), (256, 8, 32, True)])
 def test_groupnorm_kernels_on_bf16_storage(cuda, C, H, W, silu):
     """statistics, apply, image, tracker and backward read a bf16 x exactly as they read its fp32 copy"""

@@ -27,6 +27,8 @@ int launch_wino_weights(const vae_igemm_args& a, float* U, hipStream_t st);
 int launch_conv3_wino(const vae_igemm_args& a, const float* U, hipStream_t st);
 int conv3_wino_gstat_chunks(const vae_igemm_args& a);
 int conv3_wino_gnb_chunks(const vae_igemm_args& a);
+bool conv1_bf16_eligible(const vae_igemm_args& a);                      // conv1_bf16.hip (bf16 1x1 convolutions, weights resident in LDS)
+int launch_conv1_bf16(const vae_igemm_args& a, hipStream_t st);
 int conv3_tile_bf16_gstat_chunks(const vae_igemm_args& a);
 bool conv3_upwino_eligible(const vae_igemm_args& a);                    // conv3_upwino.hip (fp32 upsampler convolution, 9 positions)
 int launch_upwino_weights(const vae_igemm_args& a, float* U, hipStream_t st);
@@ -938,6 +940,8 @@ extern "C" int vae_igemm_kernel_name(const vae_igemm_args* ap, char* buf, int32_
              tf[a.A16 != nullptr]);
   else if (a.prec != VAE_PREC_BF16 && rows_use_tile(a, vec, bkm))
     snprintf(buf, n, "conv3_tile_kernel<%s,%s,%s,%d>", tf[bkm], tf[a.g.mode == VAE_MODE_DGRAD], tf[a.g.mode == VAE_MODE_UP2X], a.xf);
+  else if (a.prec == VAE_PREC_BF16 && vec && !vae_opt().flat_conv && conv1_bf16_eligible(a))
+    snprintf(buf, n, "conv1_bf16_kernel<%s,%d>", tf[a.g.mode == VAE_MODE_DGRAD], a.K / 16);
   else if (a.prec == VAE_PREC_BF16 && vec)
     snprintf(buf, n, "igemm_rows_bf16_kernel<%s,%s,%d>", a.N <= 32 ? "128,32,4,1" : "128,128,4,2", tf[bkm], a.xf);
   else if (a.N <= 32)
@@ -1047,7 +1051,9 @@ extern "C" int vae_igemm_rows(const vae_igemm_args* ap, void* stream) {
               "igemm_rows: operand too large for 32-bit byte offsets");
   }
   int rc;
-  if (a.prec == VAE_PREC_BF16 && vec) {
+  if (a.prec == VAE_PREC_BF16 && vec && !vae_opt().flat_conv && conv1_bf16_eligible(a)) {
+    rc = launch_conv1_bf16(a, st);
+  } else if (a.prec == VAE_PREC_BF16 && vec) {
     VAE_CHECK(!bkm || a.xf == VAE_XF_NONE, "igemm_rows: xf unsupported with n-contiguous weights");
     rc = launch_rows_bf16(a, bkm, st);
   } else {
