@@ -753,7 +753,7 @@ extern "C" int vae_wgrad_plan(const vae_wgrad_args* ap, int32_t* nsplit, int32_t
     return VAE_OK;
   }
   const int64_t tiles = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.g.taps;
-  const int64_t ns = std::max<int64_t>(1, std::min<int64_t>(1024 / std::max<int64_t>(tiles, 1), a.npix / 256));
+  const int64_t ns = std::max<int64_t>(1, std::min<int64_t>(512 / std::max<int64_t>(tiles, 1), a.npix / 256));
   *nsplit = (int32_t)ns;
   *xf_fusable = xf_wgrad_ok(a.g, a.npix, (int)ns, a.N) ? 1 : 0;
   return VAE_OK;
