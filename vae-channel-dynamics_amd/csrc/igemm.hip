@@ -1070,10 +1070,10 @@ extern "C" int vae_wgrad_wino_plan(const vae_wgrad_args* ap, int32_t* nsplit) {
   VAE_CHECK(ap && nsplit, "wgrad_wino_plan: null argument");
   *nsplit = 0;
   if (vae_opt().flat_conv || vae_opt().no_wino) return VAE_OK;
-  if (wgrad3_upwino_eligible(*ap)) {  // the upsampler convolution: 9 positions, two 8-wave workgroups per CU
+  if (wgrad3_upwino_eligible(*ap)) {  // the upsampler convolution: 9 positions, one 8-wave workgroup per CU (158 registers)
     const int64_t units = wgrad3_upwino_units(ap->g);
     const int64_t wgs = (int64_t)(ap->M / 128) * (ap->N / 32);
-    *nsplit = (int32_t)std::max<int64_t>(1, std::min<int64_t>(512 / std::max<int64_t>(wgs, 1), units / 8));
+    *nsplit = (int32_t)std::max<int64_t>(1, std::min<int64_t>(256 / std::max<int64_t>(wgs, 1), units / 8));
     return VAE_OK;
   }
   if (!wgrad3_wino_eligible(*ap)) return VAE_OK;
