@@ -16,15 +16,17 @@
 //     16-byte A fragment row read covers the chunk (k = 4*half + s over 4 MFMAs) against NB B fragments (channel blocks):
 //     8 NB MFMAs per wave and step.  The GroupNorm scale / shift rows of the image sit in LDS (read when a halo is stored).
 //   * The B fragment of (position, channel block) is 16 contiguous bytes per lane of the U image, and only the wave that owns
-//     the position needs it: U goes from L2 straight into registers, one step ahead (two register sets), never through LDS.
-//     One barrier per step (it publishes the next V); the two waves of a SIMD run the step in opposite order (stage then
-//     multiply / multiply then stage) so the matrix pipe has work while V is being transformed.
+//     the position needs it: U goes from L2 straight into registers, never through LDS -- ONE register set: the fragment for
+//     step s+1 is requested right behind the four MFMAs that consumed step s's.  One barrier per step (it publishes the next
+//     V); the two waves of a SIMD run the step in opposite order (stage then multiply / multiply then stage) so the matrix
+//     pipe has work while V is being transformed -- as two separate copies of the loop, which keeps hipcc's wait counts exact.
 //   * Epilogue: the 16 positions of an output tile sit in 8 different waves, so the accumulators go through LDS one
 //     32-channel block at a time ([16][32 tiles][32 co], over the V buffers), then each thread takes A^T M A of its
 //     (tile, channel) pairs, adds bias / residual and writes the 2x2 outputs (lanes along channels: 128-byte rows).
 // Numerics: the transforms only add / subtract / halve; measured against the direct kernels 1e-6 of the output scale
 // (tests/test_kernels_gpu.py), far inside the 1e-4 bar.  The epilogue also leaves the GroupNorm centred moments of the outputs
-// (one chunk per workgroup tile, as the direct kernels do); a tracked output stays on the direct kernel.
+// (one chunk per workgroup tile, as the direct kernels do) and -- dgrad launches with gnb_* set -- the first pass of the GroupNorm
+// backward over the gradient it has just computed; a tracked output stays on the direct kernel.
 #include "common.h"
 #include <type_traits>
 #include <algorithm>
