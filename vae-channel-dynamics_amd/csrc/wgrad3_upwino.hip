@@ -16,7 +16,8 @@
 // writes OHWI.  Workgroup = 8 waves = 32 ci x 128 co x 9 positions: wave w owns position w (all four 32-channel blocks of co), and
 // the NINTH position is split by channel block over waves 0..3 -- one per SIMD (wave k of a workgroup runs on SIMD k % 4), so every
 // SIMD carries 36 MFMAs per step.  (A first version with one position per wave and 9 waves put three waves of every workgroup
-// on SIMD 0: 0.51 of the matrix peak.)  Two workgroups per CU (128 VGPRs).
+// on SIMD 0: 0.51 of the matrix peak.)  One workgroup per CU at 158 registers (a 128-register build spilled 27, with scratch reloads
+// inside the loop); two staging register sets, the next-but-one unit requested behind the first channel block's MFMAs.
 #include "common.h"
 #include <algorithm>
 #include <type_traits>
