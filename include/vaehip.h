@@ -38,8 +38,11 @@ int vae_sizeof_args(int32_t which);
 /* Process-wide kernel-selection switches (no launch path reads the environment): "flat_conv" (flat implicit-GEMM kernels
  * everywhere: the second algorithm of the two-algorithm tests), "no_wino" (fp32: the direct halo-tile kernels instead of the
  * Winograd ones: the parity reference), "no_wide" (bf16: the 128-pixel halo-tile kernel instead of the wide-tile one).
- * Initial values come from VAEHIP_FLAT_CONV / VAEHIP_NO_WINO / VAEHIP_NO_WIDE, read ONCE when the library is loaded.
- * vae_get_option returns the value, or -1 for an unknown name. */
+ * One option is a count, not a switch: "wide_reserved_cus" (0..128, default 0): the persistent bf16 wide-tile kernel launches
+ * 256 - n workgroups instead of one per CU, leaving n CUs to RCCL's workgroups while gradient buckets are in flight
+ * (data-parallel runs: reference src/train.py:204-211); any grid covers all tiles, so results do not depend on it.
+ * Initial values come from VAEHIP_FLAT_CONV / VAEHIP_NO_WINO / VAEHIP_NO_WIDE / VAEHIP_WIDE_RESERVED_CUS, read ONCE when the
+ * library is loaded.  vae_get_option returns the value, or -1 for an unknown name. */
 int vae_set_option(const char* name, int32_t value);
 int vae_get_option(const char* name);
 
@@ -265,7 +268,9 @@ int vae_gn_bwd_partial(const void* x, int32_t x_bf16, const void* g, const float
                        const float* gamma, const float* beta, int32_t B, int32_t HW, int32_t C, int32_t G,
                        int32_t nchunk, int32_t silu, int32_t g_bf16, float* ws, void* stream);
 /* stage 2: dgamma/dbeta [C] (written, not accumulated) and coefficients
- * coef [B][G][2] = {rstd*s2/N, rstd*s1/N}; one launch (ws is only read)                                                  */
+ * coef [B][G][2] = {rstd*s2/N, rstd*s1/N}; one launch (ws is only read).
+ * Shapes: C <= 1024, channels per group C / G in {1, 2, 4, 8, 16} and G % 4 == 0 (one workgroup finishes 4 groups; SDXL-VAE:
+ * G = 32, C / G in {4, 8, 16}); anything else returns VAE_EINVAL with the reason in vae_last_error()                        */
 int vae_gn_bwd_final(const float* ws, const float* rstd, const float* gamma, int32_t B, int32_t HW,
                      int32_t C, int32_t G, int32_t nchunk, float* dgamma, float* dbeta, float* coef,
                      void* stream);

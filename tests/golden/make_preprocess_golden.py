@@ -2,6 +2,10 @@
 (reference src/data_utils.py:24-30: Resize(bilinear) -> CenterCrop -> RGB -> ToTensor -> Normalize(0.5, 0.5)) makes of
 them.  torchvision is not installed in this image, so the chain is evaluated with Pillow directly -- the library
 torchvision's Resize / CenterCrop call for PIL inputs -- through this repo's data_utils.get_transform (Pillow 12.2.0).
+PARITY STATUS: Pillow's 8-bit resampler IS the arithmetic torchvision runs for PIL inputs, so the pixel values are pinned
+by Pillow itself.  The Resize / CenterCrop GEOMETRY (truncated long side, half-to-even crop margin) comes from this repo's
+own data_utils, restated from torchvision's published formulas and hand-checked on the cases marked below: against
+torchvision itself it is **parity unpinned** (torchvision is not importable here and the reference holds no fixture).
 Run from the repo root:  python tests/golden/make_preprocess_golden.py"""
 import os
 import sys

@@ -257,6 +257,13 @@ def test_fp32_activation_image_policy(monkeypatch):
     from vaehip import ops
     assert ops.PRECISION == ops.PREC_F32 and ops.WINOGRAD
     assert ops.get_option("no_wino") == 0 and ops.get_option("flat_conv") == 0 and ops.get_option("bogus") == -1
+    # "wide_reserved_cus" is a count (CUs the persistent bf16 kernel leaves to RCCL), range-checked by the library
+    assert ops.get_option("wide_reserved_cus") == 0
+    with ops.option("wide_reserved_cus", 32):
+        assert ops.get_option("wide_reserved_cus") == 32
+    assert ops.get_option("wide_reserved_cus") == 0
+    with pytest.raises(RuntimeError, match="wide_reserved_cus"):
+        ops.lib.call("vae_set_option", b"wide_reserved_cus", 500)
     ok = lambda kind, shape, co, ci: ops.act_image32_ok(kind, shape, co, ci)
     assert ok("c3", (2, 32, 32, 128), 128, 128) and ok("c3", (16, 64, 64, 512), 512, 512) and ok("c3", (1, 8, 16, 256), 64, 256)
     assert not ok("c3", (2, 32, 32, 64), 128, 64)        # below the channel threshold

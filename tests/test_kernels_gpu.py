@@ -763,6 +763,13 @@ def test_bf16_wide_tile_kernel(cuda, bf16_mode, packed_weights, B, H, W, Ci, Co)
         y2 = ops.conv_fwd(xd, wd, bias.cuda(), "c3", xf=ops.XF_AFFINE_SILU, stats=st, res=_nhwc(res), a16=a16)
         dx2 = ops.conv_dgrad(dy16, wd, "c3", (H, W))
     assert _rel(y2, y) < 1e-5 and _rel(dx2, dx) < 1e-5
+    # library option "wide_reserved_cus" (CUs left to RCCL in data-parallel runs): a smaller persistent grid deals the same
+    # tiles to fewer workgroups -- bitwise the same tensor and statistics
+    with ops.option("wide_reserved_cus", 24):
+        assert ops.get_option("wide_reserved_cus") == 24
+        y0r = ops.conv_fwd(xd, wd, bias.cuda(), "c3", xf=ops.XF_AFFINE_SILU, stats=st, a16=a16, gstat_groups=32)
+    assert ops.get_option("wide_reserved_cus") == 0
+    assert torch.equal(y0r, y0) and torch.equal(y0r._gstat[0], y0._gstat[0])
 
 
 @pytest.mark.parametrize("ratio", [30.0, 1000.0])

@@ -11,5 +11,8 @@ struct vae_options {
   int flat_conv;  // flat implicit-GEMM kernels everywhere (the second algorithm of the two-algorithm tests)
   int no_wino;    // fp32: direct halo-tile kernels instead of the Winograd ones (the parity reference)
   int no_wide;    // bf16: the 128-pixel halo-tile kernel instead of the wide-tile one
+  // bf16, data parallel: the persistent wide-tile kernel launches (256 - n) workgroups instead of one per CU, leaving n CUs
+  // to RCCL's workgroups while gradient buckets are in flight (0 = all 256; a count 0..128, not a switch)
+  int wide_reserved_cus;
 };
 const vae_options& vae_opt();

@@ -18,9 +18,11 @@
 namespace {
 
 constexpr int C1_NT = 256, C1_BN = 128;
+// K = 16 * KG <= 128: compiled for two workgroups per CU (<= 256 registers per wave); the launch computes its grid from the same predicate
+#define C1_TWO_PER_CU(KG) ((KG) <= 8)
 
 template <bool DG, int KG>  // KG = K / 16
-__global__ __launch_bounds__(C1_NT, (KG <= 8 ? 2 : 1)) void conv1_bf16_kernel(vae_igemm_args p, int nblocks, int wpn) {
+__global__ __launch_bounds__(C1_NT, (C1_TWO_PER_CU(KG) ? 2 : 1)) void conv1_bf16_kernel(vae_igemm_args p, int nblocks, int wpn) {
   constexpr int K = KG * 16;
   constexpr int LDB = DG ? (C1_BN + 32) : (K + 8);  // dgrad rows: 320 B (64 B mod 256 B: conflict-free transposing reads); forward: K + 8
   extern __shared__ __attribute__((aligned(16))) u16 sB[];

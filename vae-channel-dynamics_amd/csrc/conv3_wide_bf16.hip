@@ -535,7 +535,9 @@ static int launch_wide(const vae_igemm_args& a, int tx, int ty, int64_t nt, int 
     }
     attr_set = true;
   }
-  dim3 grid((unsigned)std::min<int64_t>(nt, 256));  // persistent: one 4-wave workgroup per CU
+  // persistent: one 4-wave workgroup per CU; library option "wide_reserved_cus" leaves that many CUs free (RCCL's workgroups
+  // under a data-parallel backward pass): tiles are dealt t = blockIdx.x, += gridDim.x, so any grid size covers them all
+  dim3 grid((unsigned)std::min<int64_t>(nt, 256 - vae_opt().wide_reserved_cus));
   hipLaunchKernelGGL(kern, grid, dim3(NT), LDS_BYTES, st, a, tx, ty, (int)nt, kh0, kw0);
   return 0;
 }

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(GNT, 2) void wgrad3_upwino_kernel(vae_wgrad_args p,
     }
     const int hy = i - 1 + xr, hx = x0 - 1 + xc;
     const bool xin = ok && xrole && ((unsigned)hy < (unsigned)g.Hs) && ((unsigned)hx < (unsigned)g.Ws);
-    r.rx = VAE_BUF_LOAD4(rsX, xin ? (unsigned)((((b * g.Hs + hy) * g.Ws + hx) * g.Cs + n0 + 4 * xq) * 4) : BUF_OOB);
+    r.rx = VAE_BUF_LOAD4(rsX, xin ? (unsigned)(((b * g.Hs + hy) * g.Ws + hx) * g.Cs + n0 + 4 * xq) * 4u : BUF_OOB);  // (unsigned before the * 4: descriptors reach 4 GiB)
     const unsigned baseY = (unsigned)((b * g.Ho + 2 * i) * g.Wo + 2 * x0 + xx) * (unsigned)p.ldy * 4u + (unsigned)(m0 + 4 * yq) * 4u;
 #pragma unroll
     for (int a = 0; a < 2; ++a) r.ry[a] = VAE_BUF_LOAD4(rsY, ok ? baseY + a * rowY : BUF_OOB);

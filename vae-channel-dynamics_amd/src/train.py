@@ -165,12 +165,16 @@ def agreed_batches(loader, world: int):
         cur = next(it)
     except StopIteration:
         return
-    tok = start(cur)
-    for nxt in it:
-        ntok = start(nxt)
-        yield cur, finish(tok), False
-        cur, tok = nxt, ntok
-    yield cur, finish(tok), True
+    tok = ntok = start(cur)
+    try:
+        for nxt in it:
+            ntok = start(nxt)
+            yield cur, finish(tok), False
+            cur, tok = nxt, ntok
+        yield cur, finish(tok), True
+    finally:  # a consumer that stops early (max_train_steps) leaves one look-ahead all-reduce in flight: complete it here,
+        if ntok is not None and ntok[2] is not None:  # before the caller's barrier / destroy_process_group
+            ntok[2].wait()
 
 
 def valid_batch(batch) -> bool:

@@ -586,6 +586,12 @@ def conv_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], kin
 GNB_EPILOGUE = True  # GroupNorm-backward partial sums from the dgrad epilogue where the serving kernel has one (vae_conv_gnb_chunks)
 
 
+def _gnb_key(x, st, gamma, beta, silu) -> tuple:
+    """identity of the GroupNorm(+SiLU) a dgrad epilogue's backward sums were computed for: input, statistics, affine
+    parameters, activation flag and shape"""
+    return (x.data_ptr(), st.mean.data_ptr(), st.rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), bool(silu), tuple(x.shape))
+
+
 class GnCtx(NamedTuple):
     """the GroupNorm (+SiLU) whose output the convolution read: what its backward needs besides dL/d(output)"""
     x: torch.Tensor       # the GroupNorm input, NHWC, as stored
@@ -657,7 +663,8 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, kind: str, in_hw: Tuple[int, i
     out = torch.empty((B, Hr, Wr, Ci), device=src.device, dtype=torch.bfloat16 if o16 else torch.float32)
     a.C = _p(out)
     wu = _wino(a, src.device)
-    if gnb is not None and GNB_EPILOGUE and not pool and gnb.x.shape == out.shape:
+    # (a result that is re-stored as bf16 below drops its attributes: no sums are computed for it)
+    if gnb is not None and GNB_EPILOGUE and not pool and gnb.x.shape == out.shape and not (want16 and out.dtype != torch.bfloat16):
         a.gnb_x, a.gnb_x_bf16 = _p(gnb.x), _b16(gnb.x)
         a.gnb_mean, a.gnb_rstd, a.gnb_gamma, a.gnb_beta = _p(gnb.st.mean), _p(gnb.st.rstd), _p(gnb.gamma), _p(gnb.beta)
         a.gnb_groups, a.gnb_silu = int(gnb.groups), int(gnb.silu)
@@ -665,7 +672,8 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, kind: str, in_hw: Tuple[int, i
         if nch > 0:
             ws = torch.empty((B, nch, Ci, 2), device=src.device, dtype=torch.float32)
             a.gnb_ws = _p(ws)
-            out._gnb = (ws, nch, gnb.x.data_ptr())
+            # (what the sums belong to: gn_bwd takes them only for exactly this GroupNorm, see _gnb_key)
+            out._gnb = (ws, nch, _gnb_key(gnb.x, gnb.st, gnb.gamma, gnb.beta, gnb.silu))
         else:
             a.gnb_x = None
     _launch_igemm(a)
@@ -925,7 +933,7 @@ def gn_bwd(x: torch.Tensor, g: torch.Tensor, st: Stats, gamma: torch.Tensor, bet
     dx16 = torch.empty(x.shape, device=dev, dtype=torch.bfloat16) if want16 else None
     s = _stream()
     fused = getattr(g, "_gnb", None)  # the dgrad that produced g left the first pass's sums (conv_dgrad(gnb=...))
-    if fused is not None and fused[2] == x.data_ptr():
+    if fused is not None and fused[2] == _gnb_key(x, st, gamma, beta, silu):
         ws, nch = fused[0], fused[1]
     else:
         nch = _gn_nchunk(B, HW, Cc)
