@@ -143,7 +143,30 @@ def test_other_fp32_conv_paths_match_oracle(pair, monkeypatch, R, B, klw, path):
         monkeypatch.setattr(ops, "ACT_IMAGE32_MIN_CIN", 10 ** 9)
     else:
         monkeypatch.setattr(ops, "WINOGRAD", False)
+    prof = ops.LaunchProfiler()
+    monkeypatch.setattr(ops, "PROFILER", prof)
     test_forward_backward_matches_oracle(pair, R, B, klw)
+    monkeypatch.setattr(ops, "PROFILER", None)
+    # which kernels served the step (a test that passes on the DEFAULT path would prove nothing about the alternative):
+    names = {}
+    for rec in prof.records:
+        names[rec[0]] = names.get(rec[0], 0) + 1
+    wino_fused = sum(n for k, n in names.items() if k.startswith(("conv3_wino_kernel<2,", "conv3_wino_kernel<1,", "wgrad3_wino_kernel<2>", "wgrad3_wino_kernel<1>")))
+    wino_plain_fwd = sum(n for k, n in names.items() if k.startswith("conv3_wino_kernel<0,"))
+    wino_any = sum(n for k, n in names.items() if "wino" in k and "reduce" not in k)
+    direct = sum(n for k, n in names.items() if k.startswith(("conv3_tile_kernel", "wgrad3_tile_kernel")))
+    if path == "winograd_fused_transform":
+        # GroupNorm+SiLU applied inside the Winograd kernels' halo staging (xf template argument 2) in the forward AND the weight
+        # gradient of every resnet convolution they take; the launches left on the untransformed instantiation <0,..> are the
+        # dgrads (their operand is a gradient: nothing to transform)
+        n_fwd_fused = sum(n for k, n in names.items() if k.startswith("conv3_wino_kernel<2,"))
+        n_wg_fused = sum(n for k, n in names.items() if k.startswith("wgrad3_wino_kernel<2>"))
+        assert n_fwd_fused > 0 and n_wg_fused > 0, names
+        assert wino_plain_fwd <= n_fwd_fused, names   # at most one dgrad per fused forward: no forward ran on a materialised input
+        assert sum(n for k, n in names.items() if k.startswith("wgrad3_wino_kernel<0>")) == 0, names
+    else:
+        assert wino_any == 0 and direct > 0, names
+    _record("kernels_served", f"R={R},B={B},path={path}", names)
 
 
 def test_autograd_path_equals_fast_path(pair):

@@ -49,18 +49,43 @@ def scenario(cuda):
     return g, w, tr, mon, steps, logs, val
 
 
+def _record(name, data):
+    """measured deviations -> gpurun_out/host_gpu_measured.json (copied to profiles/ by hand when it is to be judged)"""
+    path = os.path.join(ROOT, "gpurun_out", "host_gpu_measured.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        cur = json.load(open(path)) if os.path.exists(path) else {}
+        cur[name] = data
+        json.dump(cur, open(path, "w"), indent=1)
+    except OSError:
+        pass
+
+
+# Tolerances after optimizer updates are CALIBRATED, not asserted (tools/calibrate_post_update_tolerances.py ->
+# profiles/r04_post_update_drift.json): the fp32 CPU oracle drifts from the same scenario in float64 by <= 3.8e-5 on every scalar
+# of steps 1-4 (the gradient norm; the KL by 1.2e-5 at step 3, 1e-7 before any update), 7.5e-6 on the validation sums and
+# 1.2e-5 on the step-4 tracker vectors, so two correct fp32 implementations differ by <= 2 x that < 1e-4: north_star's 1e-4
+# holds for all four steps and no extra headroom is granted (round 3 allowed 1e-3 / 2e-3 without a measurement).
+TOL_SCALARS = 1e-4
+TOL_VALIDATION = 1e-4
+TOL_TRACKER = 1e-4
+
+
 def test_train_steps_match_golden(scenario):
     g, w, tr, mon, steps, logs, val = scenario
+    meas = []
+    for s, (got, ref) in enumerate(zip(steps, g["steps"]), start=1):
+        meas.append({k: abs(got[k] - ref[k]) / abs(ref[k]) for k in ("rec", "kl", "total", "grad_norm")})
+    vm = {k: abs(val[k] - g["val"][k]) / abs(g["val"][k]) for k in ("rec_sum", "kl_sum")}
+    chk = float(w.vae.arena.flat.double().abs().sum())
+    _record("train_steps_vs_golden_rel", {"steps": meas, "validation": vm,
+                                         "param_abs_checksum": abs(chk - g["param_abs_checksum_after"]) / g["param_abs_checksum_after"]})
     for s, (got, ref) in enumerate(zip(steps, g["steps"]), start=1):
         for k in ("rec", "kl", "total", "grad_norm"):
-            # north_star: 1e-4 relative in fp32; steps 3-4 come after optimizer updates (Adam's early sign-like
-            # update amplifies last-bit gradient differences), so they get 10x headroom
-            tol = 1e-4 if s <= 2 else 1e-3
-            assert abs(got[k] - ref[k]) <= tol * abs(ref[k]), (s, k, got[k], ref[k])
+            assert abs(got[k] - ref[k]) <= TOL_SCALARS * abs(ref[k]), (s, k, got[k], ref[k])
         assert got["lr"] == pytest.approx(ref["lr"], rel=1e-12, abs=1e-15)
-    assert val["rec_sum"] == pytest.approx(g["val"]["rec_sum"], rel=1e-3)
-    assert val["kl_sum"] == pytest.approx(g["val"]["kl_sum"], rel=1e-3)
-    chk = float(w.vae.arena.flat.double().abs().sum())
+    assert val["rec_sum"] == pytest.approx(g["val"]["rec_sum"], rel=TOL_VALIDATION)
+    assert val["kl_sum"] == pytest.approx(g["val"]["kl_sum"], rel=TOL_VALIDATION)
     assert chk == pytest.approx(g["param_abs_checksum_after"], rel=1e-5)
 
 
@@ -72,7 +97,7 @@ def test_fused_tracker_and_classifier_match_reference(scenario):
     assert set(logs) == {"2", "4"}
     for s, d in ref["step_logs"].items():
         assert set(d) == set(logs[s])
-    worst = 0.0
+    worst, per_key = 0.0, {}
     for key in arr.files:
         if not key.startswith("track/"):
             continue
@@ -82,7 +107,10 @@ def test_fused_tracker_and_classifier_match_reference(scenario):
         refv = arr[key].astype(np.float64)
         rel = float(np.max(np.abs(got - refv) / (np.abs(refv) + 1e-12)))
         worst = max(worst, rel)
-        assert rel < (1e-4 if int(s) <= 2 else 2e-3), (key, rel)
+        per_key[key] = rel
+    _record("tracker_vs_reference_rel", per_key)
+    for key, rel in per_key.items():
+        assert rel < TOL_TRACKER, (key, rel)
     print("worst tracker rel err", worst)
     # step-2 statistics (before any parameter divergence): inactivity masks identical to the reference classifier's
     data2 = mon.get_data_for_step(2)
