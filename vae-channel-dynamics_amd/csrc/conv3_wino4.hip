@@ -1,0 +1,518 @@
+// Winograd F(4x4, 3x3) for the fp32 forward and dgrad of the 3x3 stride-1 layers: 36 multiplications per 4x4 output tile and
+// channel pair instead of 144 (4x fewer MFMA passes than the direct convolution, 1.78x fewer than F(2x2,3x3) in conv3_wino.hip),
+// exact fp32 products on v_mfma_f32_32x32x2_f32.
+//     Y = A^T [ sum_ci (G g G^T) (.) (B^T d B) ] A          d: 6x6 input patch, g: 3x3 kernel, Y: 4x4 outputs
+// with Lavin's matrices for the points (0, +-1, +-2, inf).  Accuracy: tools/wino_f4_error_study.py (CPU emulation in fp32 on
+// the operands of the oracle's R = 64 step, against float64): a layer's output / input gradient 4e-6..1.3e-5 of its max (F(2x2):
+// 5e-7), the whole step's losses unchanged (2e-7), worst gradient tensor 3.3e-5 of its own max (F(2x2): 1.9e-5, direct fp32:
+// 1.6e-5), tracked statistics 9e-7 -- inside the bars of tests/test_engine_gpu.py (profiles/r04_wino_f4_error_study.json).
+//
+// Per position (xi, nu) of the 6x6 transform domain the product summed over input channels is a GEMM
+//     M[pos][tile][co] = sum_ci V[pos][tile][ci] * U[pos][co][ci]
+//   * Workgroup = 12 waves (3 per SIMD, <= 168 registers) = 16 x 32 output pixels (32 tiles of 4x4) x 64 output channels, channel
+//     chunks of 8 per step; ONE workgroup per CU (the 36 x 32 x 64 accumulators are 295 KB of the CU's 512 KB register file).
+//     Wave w owns positions 3w .. 3w+2 for both 32-channel blocks: 24 MFMAs per wave and step, 96 accumulator registers.
+//   * U = G g G^T built per launch from the LIVE weights (vae_wino_weights), [K/8][36][N][8]: the B fragment of (position,
+//     channel block) is 16 contiguous bytes per lane, requested by the one wave that owns the position straight from L2 into
+//     registers (one register set, re-requested right behind the MFMAs that consumed it), never through LDS.
+//   * The chunk's 18 x 34 input halo is loaded once (GroupNorm + SiLU applied once per element) two steps ahead, as 8 CHANNEL
+//     PLANES of 641 floats in LDS (641 = 1 mod 32: the 8 tile columns x 4 channels a 32-lane group reads are 32 different banks;
+//     a pixel-major image would put every tile on the same 8 banks).  All 768 threads transform: thread = (tile, channel, row
+//     pair): rows {1,2}, {3,4} or {0,5} of B^T d (they share their sub-expressions pairwise), then those two rows times B: 48
+//     operations, 12 values written to the V image [36][2 k-halves][32 tiles][4] (a wave's A-fragment read of one position is
+//     1 KB, conflict-free for ds_read_b128).
+//   * One barrier per step.  The three waves of a SIMD are w, w+4, w+8: waves 4..7 multiply first and stage afterwards, the
+//     others stage first, so the matrix pipe has work while V is being built (separate copies of the loop per order: exact
+//     wait counts, conv3_wino.hip).
+//   * Epilogue per 32-channel block: accumulators through LDS ([36][32 tiles][33]), each thread takes A^T M A of its (tile,
+//     channel) pairs, adds bias / residual, writes the 4x4 outputs (lanes along channels: 128-byte rows) and leaves the
+//     GroupNorm moments of the outputs / -- dgrad launches -- the first pass of the GroupNorm backward, as conv3_wino.hip does.
+#include "common.h"
+#include <type_traits>
+#include <algorithm>
+
+namespace {
+
+constexpr int FTH = 16, FTW = 32;        // output pixels per workgroup tile
+constexpr int FNTL = 32;                 // tiles per workgroup (4 rows x 8 columns of 4x4 outputs)
+constexpr int FBK = 8;                   // channels per step
+constexpr int FNT = 768;                 // 12 waves
+constexpr int FPOS = 36;
+constexpr int FBN = 64;                  // output channels per workgroup
+constexpr int FSV = FPOS * FNTL * FBK;   // floats per V buffer (36,864 B)
+constexpr int FHW = 34, FHH = 18;        // halo of the tile
+constexpr int FHP = FHW * FHH;           // 612 pixels
+constexpr int FPL = 641;                 // floats per channel plane of the halo image (= 1 mod 32)
+constexpr int FSH = FBK * FPL;           // floats per halo buffer (20,512 B)
+constexpr int FSS = 2 * 1024;            // GroupNorm scale / shift rows of the image (K <= 1024)
+constexpr int FMLD = 33;                 // epilogue image row (floats)
+constexpr int FSM = FPOS * FNTL * FMLD + 12 * 8 * 2 + 24 * 32 * 2;  // epilogue image + statistics scratch + GroupNorm-backward sums
+constexpr int FMAIN = 2 * FSV + 2 * FSH + FSS;
+constexpr int F_LDS = (FSM > FMAIN ? FSM : FMAIN) * 4;  // 158,976 B
+static_assert(F_LDS <= 160 * 1024, "LDS");
+
+// U[pos][n][k] = (G g G^T)[pos] for g = W[n][.][.][k] (forward) or g = rot180(W[k][.][.][n]) (dgrad); layout [K/8][36][N][8]
+__global__ __launch_bounds__(256) void wino4_weights_kernel(const float* __restrict__ W, int N, int K, int dgrad, int64_t sn, int64_t sk, int64_t st,
+                                                            float* __restrict__ U) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)N * K) return;
+  const int k = (int)(i % K), n = (int)(i / K);
+  float g[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const int tap = dgrad ? (2 - a) * 3 + (2 - b) : a * 3 + b;
+      g[a][b] = W[(int64_t)n * sn + (int64_t)k * sk + (int64_t)tap * st];
+    }
+  constexpr float c4 = 0.25f, c6 = 1.0f / 6.0f, c12 = 1.0f / 12.0f, c24 = 1.0f / 24.0f;
+  float t[6][3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {  // G g
+    const float g0 = g[0][b], g1 = g[1][b], g2 = g[2][b];
+    t[0][b] = c4 * g0;
+    t[1][b] = -c6 * ((g0 + g2) + g1);
+    t[2][b] = -c6 * ((g0 + g2) - g1);
+    t[3][b] = (c24 * g0 + c6 * g2) + c12 * g1;
+    t[4][b] = (c24 * g0 + c6 * g2) - c12 * g1;
+    t[5][b] = g2;
+  }
+  float* o = U + ((int64_t)(k >> 3) * FPOS * N + n) * 8 + (k & 7);
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {  // (G g) G^T
+    const float g0 = t[a][0], g1 = t[a][1], g2 = t[a][2];
+    float u[6];
+    u[0] = c4 * g0;
+    u[1] = -c6 * ((g0 + g2) + g1);
+    u[2] = -c6 * ((g0 + g2) - g1);
+    u[3] = (c24 * g0 + c6 * g2) + c12 * g1;
+    u[4] = (c24 * g0 + c6 * g2) - c12 * g1;
+    u[5] = g2;
+#pragma unroll
+    for (int b = 0; b < 6; ++b) o[(int64_t)(a * 6 + b) * N * 8] = u[b];
+  }
+}
+
+// one 1-D input transform B^T r of a 6-vector (also the row pass: (B^T d) B = (B^T (B^T d)^T)^T)
+__device__ __forceinline__ void bt6(const float r[6], float v[6]) {
+  v[0] = fmaf(4.f, r[0], fmaf(-5.f, r[2], r[4]));
+  const float a = fmaf(-4.f, r[2], r[4]), b = fmaf(-4.f, r[1], r[3]);
+  v[1] = a + b;
+  v[2] = a - b;
+  const float c = r[4] - r[2], e = r[3] - r[1];
+  v[3] = fmaf(2.f, e, c);
+  v[4] = fmaf(-2.f, e, c);
+  v[5] = fmaf(4.f, r[1], fmaf(-5.f, r[3], r[5]));
+}
+// one 1-D output transform A^T m of a 6-vector -> 4
+__device__ __forceinline__ void at6(const float m[6], float y[4]) {
+  const float s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+  y[0] = (m[0] + s12) + s34;
+  y[1] = fmaf(2.f, d34, d12);
+  y[2] = fmaf(4.f, s34, s12);
+  y[3] = fmaf(8.f, d34, d12) + m[5];
+}
+
+template <int XF>
+__global__ __launch_bounds__(FNT, 3) void conv3_wino4_kernel(vae_igemm_args p, const float* __restrict__ U, int tiles_x, int tiles_y, int xcd_sp) {
+  __shared__ __attribute__((aligned(16))) float wsm[F_LDS / 4];
+  float* const sV = wsm;            // [2][FSV]
+  float* const sH = wsm + 2 * FSV;  // [2][FSH]: the chunk's input halo, transformed, as channel planes
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const vae_conv_geom g = p.g;
+  const int tilesN = p.N / FBN;
+  // workgroup id -> (spatial tile, channel block): the rule of conv3_wino.hip (small U images: the channel blocks of a spatial
+  // tile get ids congruent mod 8, one XCD's L2 fetches that tile's halo once)
+  int t = blockIdx.x, tn;
+  if (xcd_sp) {
+    tn = (t >> 3) % tilesN;
+    t = ((t >> 3) / tilesN) * 8 + (t & 7);
+  } else {
+    tn = t % tilesN;
+    t /= tilesN;
+  }
+  const int tx = t % tiles_x; t /= tiles_x;
+  const int ty = t % tiles_y;
+  const int b = t / tiles_y;
+  const int y0 = ty * FTH, x0 = tx * FTW, n0 = tn * FBN;
+  const int nsteps = p.K / FBK;
+
+  // ---- halo role: item i = (pixel hp of the 18 x 34 halo, channel quad hq); thread tid owns items tid and tid + 768 (< 1224) ----
+  const auto rsA = VAE_BUF_RSRC(p.A + (int64_t)b * g.Hs * g.Ws * g.Cs, (size_t)g.Hs * g.Ws * g.Cs * 4u);
+  unsigned hbase[2];
+  int hdst[2];
+  bool hin[2], hown[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int it = tid + j * FNT;
+    const int hp = it >> 1, hq = it & 1;
+    hown[j] = it < 2 * FHP;
+    const int hy = y0 - 1 + hp / FHW, hx = x0 - 1 + hp % FHW;
+    hin[j] = hown[j] && ((unsigned)hy < (unsigned)g.Hs) && ((unsigned)hx < (unsigned)g.Ws);
+    hbase[j] = hin[j] ? (unsigned)(((hy * g.Ws + hx) * g.Cs + hq * 4) * 4) : BUF_OOB;
+    hdst[j] = hq * 4 * FPL + hp;
+  }
+  float* const sS = wsm + 2 * FSV + 2 * FSH;  // GroupNorm scale / shift rows of image b ([2][K])
+  if (XF != VAE_XF_NONE) {
+    for (int i = tid; i < p.K; i += FNT) {
+      sS[i] = p.scale[(int64_t)b * g.Cs + i];
+      sS[p.K + i] = p.shift[(int64_t)b * g.Cs + i];
+    }
+    __syncthreads();
+  }
+  struct Halo {
+    f32x4 v[2];
+  };
+  Halo rh;
+  rh.v[0] = rh.v[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto load_halo_into = [&](int step, Halo& h) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const bool ok = hin[j] && step < nsteps;
+      h.v[j] = VAE_BUF_LOAD4(rsA, ok ? hbase[j] + (unsigned)(step * FBK * 4) : BUF_OOB);
+    }
+  };
+  auto store_halo_from = [&](float* dst, const Halo& h, int step) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (!hown[j]) continue;
+      f32x4 v = h.v[j];
+      if (XF != VAE_XF_NONE) {
+        const int c = min(step, nsteps - 1) * FBK + ((tid + j * FNT) & 1) * 4;
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(&sS[c]), sh = *reinterpret_cast<const f32x4*>(&sS[p.K + c]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float u = v[e] * sc[e] + sh[e];
+          if (XF == VAE_XF_AFFINE_SILU) u = silu_f(u);
+          v[e] = (hin[j] && step < nsteps) ? u : 0.f;  // padding stays zero AFTER the transform
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dst[hdst[j] + e * FPL] = v[e];
+    }
+  };
+
+  // ---- V role (all threads): tile vt = (vty, vtx), channel vc of the chunk, row pair rg (uniform per wave: tid >> 8) ----
+  const int vtx = tid & 7, vcl = (tid >> 3) & 3, vty = (tid >> 5) & 3, vch = (tid >> 7) & 1, rg = tid >> 8;
+  const int vsrc = (vch * 4 + vcl) * FPL + (4 * vty) * FHW + 4 * vtx;              // patch origin in the halo image
+  const int vdst = (vch * FNTL + vty * 8 + vtx) * 4 + vcl;                         // + pos * (2 * FNTL * 4)
+  auto write_v = [&](const float* sHc, float* dst) {
+    const float* src = sHc + vsrc;
+    float tr[2][6];
+    int i0, i1;
+    if (rg == 0) {  // rows 1, 2 of B^T d
+      i0 = 1; i1 = 2;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const float d1 = src[1 * FHW + j], d2 = src[2 * FHW + j], d3 = src[3 * FHW + j], d4 = src[4 * FHW + j];
+        const float a = fmaf(-4.f, d2, d4), bb = fmaf(-4.f, d1, d3);
+        tr[0][j] = a + bb;
+        tr[1][j] = a - bb;
+      }
+    } else if (rg == 1) {  // rows 3, 4
+      i0 = 3; i1 = 4;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const float d1 = src[1 * FHW + j], d2 = src[2 * FHW + j], d3 = src[3 * FHW + j], d4 = src[4 * FHW + j];
+        const float c = d4 - d2, e = d3 - d1;
+        tr[0][j] = fmaf(2.f, e, c);
+        tr[1][j] = fmaf(-2.f, e, c);
+      }
+    } else {  // rows 0, 5
+      i0 = 0; i1 = 5;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const float d0 = src[j], d1 = src[1 * FHW + j], d2 = src[2 * FHW + j], d3 = src[3 * FHW + j], d4 = src[4 * FHW + j], d5 = src[5 * FHW + j];
+        tr[0][j] = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
+        tr[1][j] = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
+      }
+    }
+    float v[6];
+    bt6(tr[0], v);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) dst[(i0 * 6 + j) * (2 * FNTL * 4) + vdst] = v[j];
+    bt6(tr[1], v);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) dst[(i1 * 6 + j) * (2 * FNTL * 4) + vdst] = v[j];
+  };
+
+  // ---- U fragments: B operand of (position, channel block nb) = U[step][pos][n0 + 32 nb + lr][4 lh .. 4 lh + 3] ----
+  const auto rsU = VAE_BUF_RSRC(U, (size_t)nsteps * FPOS * p.N * 8 * 4u);
+  unsigned bvo[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) bvo[q] = (unsigned)(((n0 + q * 32 + lr) * 8 + lh * 4) * 4);
+  const unsigned bpos = (unsigned)p.N * 32u;  // bytes per position of the U image
+  f32x4 bq[6];
+  auto load_b1 = [&](int step, int i) {
+    const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(min(step, nsteps - 1) * FPOS + 3 * wave) * bpos);
+    bq[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsU, bvo[i & 1], so + (i >> 1) * bpos, 0));
+  };
+
+  f32x16 acc[3][2];
+#pragma unroll
+  for (int pi = 0; pi < 3; ++pi)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[pi][nb][e] = 0.f;
+
+  // prologue: halo(0), halo(1) in LDS, V(0) from halo(0); halo(2) and the U fragments of step 0 in registers
+#pragma unroll
+  for (int i = 0; i < 6; ++i) load_b1(0, i);
+  {
+    Halo h0, h1;
+    load_halo_into(0, h0);
+    load_halo_into(1, h1);
+    load_halo_into(2, rh);
+    store_halo_from(sH, h0, 0);
+    store_halo_from(sH + FSH, h1, 1);
+  }
+  __syncthreads();
+  write_v(sH, sV);
+  __syncthreads();
+
+  auto multiply = [&](const f32x4* a4, int s) {  // step s; requests step s+1's fragments as it goes
+#pragma unroll
+    for (int pi = 0; pi < 3; ++pi)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[pi][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[pi][e], bq[pi * 2 + nb][e], acc[pi][nb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_b1(s + 1, pi * 2 + nb);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+  };
+  auto stage_next = [&](int s, int par) {
+    if (s + 1 < nsteps) write_v(sH + (par ^ 1) * FSH, sV + (par ^ 1) * FSV);  // V(s+1): nobody reads that buffer now
+    store_halo_from(sH + par * FSH, rh, s + 2);                                // halo(s+2) over halo(s)
+    load_halo_into(s + 3, rh);
+  };
+  auto step = [&](int s, int par, auto first_c) {
+    constexpr bool STAGE_FIRST = decltype(first_c)::value;
+    const float* cV = sV + par * FSV;
+    f32x4 a4[3];
+    auto read_a = [&]() {
+#pragma unroll
+      for (int pi = 0; pi < 3; ++pi) a4[pi] = *reinterpret_cast<const f32x4*>(&cV[(((3 * wave + pi) * 2 + lh) * FNTL + lr) * 4]);
+    };
+    if (STAGE_FIRST) {
+      stage_next(s, par);
+      read_a();
+      __builtin_amdgcn_sched_barrier(0);
+      multiply(a4, s);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      read_a();
+      multiply(a4, s);
+      __builtin_amdgcn_sched_barrier(0);
+      stage_next(s, par);
+    }
+    __syncthreads();
+  };
+  auto run = [&](auto first_c) {
+    int s = 0;
+    for (; s + 1 < nsteps; s += 2) {
+      step(s, 0, first_c);
+      step(s + 1, 1, first_c);
+    }
+    if (s < nsteps) step(s, 0, first_c);
+  };
+  if (wave >= 4 && wave < 8) run(std::false_type{});  // uniform per wave: the middle wave of every SIMD multiplies first
+  else run(std::true_type{});
+
+  // ---- epilogue: per 32-channel block, M through LDS, then Y = A^T M A ----
+  float* const sM = wsm;  // [36][32 tiles][FMLD], over the V / halo buffers (the last step's barrier has passed)
+  const size_t obytes = (size_t)g.Ho * g.Wo * p.ldc * 4u;
+  const auto rsC = VAE_BUF_RSRC(p.C + (int64_t)b * g.Ho * g.Wo * p.ldc, obytes);
+  const auto rsR = VAE_BUF_RSRC((p.res ? p.res : p.C) + (int64_t)b * g.Ho * g.Wo * p.ldc, obytes);
+  const bool gnb = p.gnb_ws != nullptr;  // uniform
+  const unsigned xes = p.gnb_x_bf16 ? 2u : 4u;
+  const auto rsX = VAE_BUF_RSRC(reinterpret_cast<const char*>(gnb ? p.gnb_x : (const void*)p.C) + (int64_t)b * g.Ho * g.Wo * p.ldc * xes,
+                                (size_t)g.Ho * g.Wo * p.ldc * xes);
+  const int nrnd = tid < 1024 - FNT ? 2 : 1;  // (tile, channel) items 0..1023 of a block: thread tid takes tid and tid + 768
+  float* const red = sM + FPOS * FNTL * FMLD;  // [12 waves][groups of the 32-channel block][2]
+  float* const redb = red + 12 * 8 * 2;        // [24 slots][32 channels][2]
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+    for (int pi = 0; pi < 3; ++pi) {
+      const int pos = 3 * wave + pi;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int tile = (e & 3) + 8 * (e >> 2) + 4 * lh;
+        sM[(pos * FNTL + tile) * FMLD + lr] = acc[pi][nb][e];
+      }
+    }
+    __syncthreads();
+    const int co = tid & 31, col = n0 + nb * 32 + co;
+    const float bv = p.bias ? p.bias[col] : 0.f;
+    float gpv = 0.f, gs1 = 0.f, gs2 = 0.f;  // GroupNorm statistics of this thread's outputs of channel `col`: shifted sums
+    float bs1 = 0.f, bs2 = 0.f;             // GroupNorm backward: sum dz, sum dz * xhat over the same outputs
+    float bmu = 0.f, brs = 0.f, bga = 0.f, bbe = 0.f;
+    if (gnb) {
+      const int grp = col / (p.N / p.gnb_groups);
+      bmu = p.gnb_mean[b * p.gnb_groups + grp];
+      brs = p.gnb_rstd[b * p.gnb_groups + grp];
+      bga = p.gnb_gamma[col];
+      bbe = p.gnb_beta[col];
+    }
+#pragma unroll 1
+    for (int rnd = 0; rnd < nrnd; ++rnd) {
+      const int tile = (tid >> 5) + 24 * rnd;
+      const int oy = y0 + 4 * (tile >> 3), ox = x0 + 4 * (tile & 7);
+      const unsigned obase = (unsigned)(((oy * g.Wo + ox) * p.ldc + col) * 4);
+      const unsigned rstep = (unsigned)(g.Wo * p.ldc * 4), cstep = (unsigned)(p.ldc * 4);
+      float rres[16];
+      if (p.res) {  // uniform: requested before the LDS reads below
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          rres[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, obase + (q >> 2) * rstep + (q & 3) * cstep, 0, 0));
+      }
+      float xin[16];
+      if (gnb) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const unsigned eo = obase + (q >> 2) * rstep + (q & 3) * cstep;
+          xin[q] = p.gnb_x_bf16 ? __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rsX, eo >> 1, 0, 0) << 16)
+                                : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX, eo, 0, 0));
+        }
+      }
+      float h[4][6];  // A^T M: per column j of M the 4 output rows
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        float m[6], y[4];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) m[i] = sM[((i * 6 + j) * FNTL + tile) * FMLD + co];
+        at6(m, y);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) h[a][j] = y[a];
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        float y[4];
+        at6(h[a], y);
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+          const int q = a * 4 + bb;
+          float v = y[bb] + bv;
+          if (p.res) v += rres[q];
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, obase + a * rstep + bb * cstep, 0, 0);
+          if (rnd == 0 && q == 0) gpv = v;
+          const float dv = v - gpv;
+          gs1 += dv;
+          gs2 += dv * dv;
+          if (gnb) {  // uniform; same arithmetic per element as gn_bwd_partial_kernel (norm.hip)
+            const float xh = (xin[q] - bmu) * brs;
+            float du = v;
+            if (p.gnb_silu) du *= silu_grad_f(xh * bga + bbe);
+            bs1 += du;
+            bs2 += du * xh;
+          }
+        }
+      }
+    }
+    if (gnb) {
+      redb[((tid >> 5) * 32 + co) * 2] = bs1;
+      redb[((tid >> 5) * 32 + co) * 2 + 1] = bs2;
+    }
+    const int cpg = p.gstat ? p.N / p.gstat_groups : 4, ng = 32 / cpg;
+    const float nlane = 16.f * (float)nrnd;  // outputs per lane (uniform per wave: waves 0..3 take two rounds)
+    if (p.gstat) {  // uniform: centred moments of the block's groups; a wave holds 2 tile slots x 32 channels
+      const MeanM2 a = mm2_wave_group(mm2_from_shifted(gpv, gs1, gs2, nlane), cpg, nlane);
+      if (lh == 0 && (lr & (cpg - 1)) == 0) {
+        red[(wave * ng + lr / cpg) * 2] = a.m;
+        red[(wave * ng + lr / cpg) * 2 + 1] = a.M2;
+      }
+    }
+    __syncthreads();
+    if (gnb && tid < 32) {  // the 24 slots of a channel, fixed order
+      float a1 = redb[tid * 2], a2 = redb[tid * 2 + 1];
+#pragma unroll
+      for (int w = 1; w < 24; ++w) {
+        a1 += redb[(w * 32 + tid) * 2];
+        a2 += redb[(w * 32 + tid) * 2 + 1];
+      }
+      float* o = p.gnb_ws + (((int64_t)b * (tiles_x * tiles_y) + ty * tiles_x + tx) * p.N + n0 + nb * 32 + tid) * 2;
+      o[0] = a1;
+      o[1] = a2;
+    }
+    if (p.gstat && tid < ng) {  // the 12 waves in fixed order: waves 0..3 hold 64 outputs per channel, the others 32
+      MeanM2 a{red[tid * 2], red[tid * 2 + 1]};
+      float na = 64.f * (float)cpg;
+#pragma unroll
+      for (int w = 1; w < 12; ++w) {
+        const float nw = (w < 4 ? 64.f : 32.f) * (float)cpg;
+        a = mm2_merge(a, na, MeanM2{red[(w * ng + tid) * 2], red[(w * ng + tid) * 2 + 1]}, nw);
+        na += nw;
+      }
+      float* o = p.gstat + (((int64_t)b * (tiles_x * tiles_y) + ty * tiles_x + tx) * p.gstat_groups + (n0 + nb * 32) / cpg + tid) * 2;
+      o[0] = a.m;
+      o[1] = a.M2;
+    }
+    __syncthreads();  // (the next block's accumulators overwrite the image and the scratch)
+  }
+}
+
+}  // namespace
+
+// forward / dgrad of a plain 3x3 stride-1 pad-1 layer in fp32, 16x32-pixel tiles, channel chunks of 8, 64 output channels per workgroup
+bool conv3_wino4_eligible(const vae_igemm_args& a) {
+  const vae_conv_geom& g = a.g;
+  if (a.prec != VAE_PREC_F32 || a.A16 != nullptr || a.batch != 1 || a.alpha != 1.0f) return false;
+  if (g.taps != 9 || g.stride != 1 || g.pad_t != 1 || g.pad_l != 1) return false;
+  if (a.tapmask != 0 || a.a_step > 1 || a.c_step > 1 || a.out_bf16 || a.track != nullptr) return false;
+  if (!(g.mode == VAE_MODE_FWD || g.mode == VAE_MODE_DGRAD) || g.Ho != g.Hs || g.Wo != g.Ws) return false;
+  if (g.mode == VAE_MODE_DGRAD && a.xf != VAE_XF_NONE) return false;
+  if (g.Ho % FTH != 0 || g.Wo % FTW != 0 || a.K % FBK != 0 || a.K < 64 || a.K > 1024 || a.N % FBN != 0 || g.Cs < a.K) return false;
+  if (!aligned16(a.A) || !aligned16(a.C)) return false;
+  if ((size_t)g.Hs * g.Ws * g.Cs * 4u >= BUF_MAX || (size_t)g.Ho * g.Wo * a.ldc * 4u >= BUF_MAX) return false;
+  if ((size_t)a.K * FPOS * a.N * 4u >= BUF_MAX) return false;
+  return true;
+}
+
+// chunks per image of the statistics epilogue (0 = not available for these arguments)
+int conv3_wino4_gstat_chunks(const vae_igemm_args& a) {
+  const vae_conv_geom& g = a.g;
+  if (a.gstat_groups <= 0 || a.N % a.gstat_groups != 0 || g.mode == VAE_MODE_DGRAD) return 0;
+  const int cpg = a.N / a.gstat_groups;
+  if (cpg != 4 && cpg != 8 && cpg != 16) return 0;
+  return (g.Wo / FTW) * (g.Ho / FTH);
+}
+
+// chunks per image of the GroupNorm-backward epilogue (0 = not available for these arguments)
+int conv3_wino4_gnb_chunks(const vae_igemm_args& a) {
+  const vae_conv_geom& g = a.g;
+  if (g.mode != VAE_MODE_DGRAD || a.gnb_x == nullptr || a.gnb_groups <= 0 || a.N % a.gnb_groups != 0 || a.ldc != a.N) return 0;
+  if (a.res != nullptr || a.bias != nullptr || a.out_bf16) return 0;
+  if ((size_t)g.Ho * g.Wo * a.ldc * 4u >= BUF_MAX) return 0;
+  return (g.Wo / FTW) * (g.Ho / FTH);
+}
+
+int launch_wino4_weights(const vae_igemm_args& a, float* U, hipStream_t st) {
+  const int64_t n = (int64_t)a.N * a.K;
+  hipLaunchKernelGGL(wino4_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.W, a.N, a.K, a.g.mode == VAE_MODE_DGRAD ? 1 : 0,
+                     a.sn, a.sk, a.st, U);
+  return 0;
+}
+
+template <int XF>
+static int launch_wino4_t(const vae_igemm_args& a, const float* U, hipStream_t st) {
+  const vae_conv_geom& g = a.g;
+  const int tx = g.Wo / FTW, ty = g.Ho / FTH;
+  const int tilesN = a.N / FBN;
+  const int64_t nt = (int64_t)tilesN * tx * ty * g.B;
+  if (nt > 0x7fffffffLL) return VAE_EINVAL;
+  constexpr size_t xcd_u = (size_t)9 << 20;  // U images up to 9 MB (36 positions; 128 and 256 channels): the channel blocks of a tile share an XCD
+  const int xcd_sp = (tilesN > 1 && (size_t)a.K * FPOS * a.N * 4u <= xcd_u && ((int64_t)tx * ty * g.B) % 8 == 0) ? 1 : 0;
+  hipLaunchKernelGGL((conv3_wino4_kernel<XF>), dim3((unsigned)nt), dim3(FNT), 0, st, a, U, tx, ty, xcd_sp);
+  return 0;
+}
+
+int launch_conv3_wino4(const vae_igemm_args& a, const float* U, hipStream_t st) {
+  if (a.xf == VAE_XF_NONE) return launch_wino4_t<VAE_XF_NONE>(a, U, st);
+  if (a.xf == VAE_XF_AFFINE) return launch_wino4_t<VAE_XF_AFFINE>(a, U, st);
+  return launch_wino4_t<VAE_XF_AFFINE_SILU>(a, U, st);
+}

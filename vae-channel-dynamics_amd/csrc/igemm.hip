@@ -34,6 +34,11 @@ bool conv3_upwino_eligible(const vae_igemm_args& a);                    // conv3
 int launch_upwino_weights(const vae_igemm_args& a, float* U, hipStream_t st);
 int launch_conv3_upwino(const vae_igemm_args& a, const float* U, hipStream_t st);
 int conv3_wino_nb();
+bool conv3_wino4_eligible(const vae_igemm_args& a);                     // conv3_wino4.hip (fp32 Winograd F(4x4,3x3))
+int launch_wino4_weights(const vae_igemm_args& a, float* U, hipStream_t st);
+int launch_conv3_wino4(const vae_igemm_args& a, const float* U, hipStream_t st);
+int conv3_wino4_gstat_chunks(const vae_igemm_args& a);
+int conv3_wino4_gnb_chunks(const vae_igemm_args& a);
 bool conv3_wide_bf16_eligible(const vae_igemm_args& a);                 // conv3_wide_bf16.hip (both operands bf16 images, 8x32 tiles)
 int conv3_wide_bf16_gstat_chunks(const vae_igemm_args& a);
 int launch_conv3_wide_bf16(const vae_igemm_args& a, hipStream_t st);
@@ -824,6 +829,9 @@ static bool rows_wino(const vae_igemm_args& a) {
   return conv3_wino_eligible(a) && rows_vec(a, bkm) && !conv_smallk_eligible(a) && !conv_smalln_eligible(a) && !vae_opt().flat_conv &&
          !vae_opt().no_wino;
 }
+// ... and of those, the layers whose maps are whole 16 x 32 tiles with whole 64-channel blocks run F(4x4,3x3) (36 positions, 36
+// instead of 64 multiplications per 4x4 outputs); library option "no_wino4" keeps them on F(2x2,3x3)
+static bool rows_wino4(const vae_igemm_args& a) { return rows_wino(a) && conv3_wino4_eligible(a) && !vae_opt().no_wino4; }
 // the upsampler convolution (forward over the virtual nearest-2x upsample, or its dgrad with the 2x2 sum-pool folded in) as the
 // 9-position scheme of conv3_upwino.hip
 static bool rows_upwino(const vae_igemm_args& a) { return conv3_upwino_eligible(a) && !vae_opt().flat_conv && !vae_opt().no_wino; }
@@ -831,7 +839,7 @@ extern "C" int vae_wino_ok(const vae_igemm_args* ap) { return (ap && (rows_wino(
 extern "C" int64_t vae_wino_weight_floats(const vae_igemm_args* ap) {
   if (!ap) return 0;
   const bool up = ap->g.mode == VAE_MODE_UP2X || ap->g.mode == VAE_MODE_UP2X_DGRAD;
-  return (int64_t)(up ? 9 : 16) * ap->N * ap->K;
+  return (int64_t)(up ? 9 : (rows_wino4(*ap) ? 36 : 16)) * ap->N * ap->K;
 }
 extern "C" int vae_wino_weights(const vae_igemm_args* ap, float* Wu, void* stream) {
   VAE_CHECK(ap && Wu && ap->W && aligned16(Wu), "wino_weights: null or unaligned pointer");
@@ -841,7 +849,7 @@ extern "C" int vae_wino_weights(const vae_igemm_args* ap, float* Wu, void* strea
     return VAE_OK;
   }
   VAE_CHECK(rows_wino(*ap), "wino_weights: the layer is not served by the Winograd kernel (vae_wino_ok)");
-  if (int rc = launch_wino_weights(*ap, Wu, (hipStream_t)stream)) return rc;
+  if (int rc = (rows_wino4(*ap) ? launch_wino4_weights : launch_wino_weights)(*ap, Wu, (hipStream_t)stream)) return rc;
   VAE_LAUNCH_CHECK("wino_weights");
   return VAE_OK;
 }
@@ -896,6 +904,7 @@ extern "C" int vae_conv_phase_ok(const vae_igemm_args* ap) {
 extern "C" int vae_conv_gnb_chunks(const vae_igemm_args* ap) {
   if (!ap) return 0;
   const vae_igemm_args a = rows_canon(*ap);
+  if (a.Wu != nullptr && rows_wino4(a)) return conv3_wino4_gnb_chunks(a);
   if (a.Wu != nullptr && rows_wino(a)) return conv3_wino_gnb_chunks(a);
   return 0;  // (the other dgrad kernels have no such epilogue yet)
 }
@@ -903,6 +912,7 @@ extern "C" int vae_conv_gnb_chunks(const vae_igemm_args* ap) {
 extern "C" int vae_conv_gstat_chunks(const vae_igemm_args* ap) {
   if (!ap) return 0;
   const vae_igemm_args a = rows_canon(*ap);
+  if (a.Wu != nullptr && rows_wino4(a)) return conv3_wino4_gstat_chunks(a);
   if (a.Wu != nullptr) return conv3_wino_eligible(a) ? conv3_wino_gstat_chunks(a) : 0;
   const bool bkm = rows_bkm(a), vec = rows_vec(a, bkm);
   if ((a.A16 == nullptr && conv_smallk_eligible(a)) || conv_smalln_eligible(a)) return 0;
@@ -921,6 +931,8 @@ extern "C" int vae_igemm_kernel_name(const vae_igemm_args* ap, char* buf, int32_
   const char* tf[2] = {"false", "true"};
   if (a.Wu != nullptr && rows_upwino(a))
     snprintf(buf, n, "conv3_upwino_kernel<%s>", tf[a.g.mode == VAE_MODE_UP2X_DGRAD]);
+  else if (a.Wu != nullptr && rows_wino4(a))
+    snprintf(buf, n, "conv3_wino4_kernel<%d>", a.xf);
   else if (a.Wu != nullptr && rows_wino(a))
     snprintf(buf, n, "conv3_wino_kernel<%d,%d>", a.xf, conv3_wino_nb());
   else if (rows_is_phase(a) && rows_use_wide_bf16(a, vec, bkm))
@@ -996,6 +1008,12 @@ extern "C" int vae_igemm_rows(const vae_igemm_args* ap, void* stream) {
     VAE_CHECK(aligned16(a.Wu), "igemm_rows: unaligned Wu");
     if (int rc2 = launch_conv3_upwino(a, a.Wu, st)) return rc2;
     VAE_LAUNCH_CHECK("conv3_upwino");
+    return VAE_OK;
+  }
+  if (a.Wu != nullptr && rows_wino4(a)) {  // Winograd F(4x4,3x3): Wu holds 36 positions (vae_wino_weights built it under the same options)
+    VAE_CHECK(aligned16(a.Wu), "igemm_rows: unaligned Wu");
+    if (int rc2 = launch_conv3_wino4(a, a.Wu, st)) return rc2;
+    VAE_LAUNCH_CHECK("conv3_wino4");
     return VAE_OK;
   }
   if (a.Wu != nullptr) {  // Winograd F(2x2,3x3) with the transformed weights the caller built for THIS geometry

@@ -59,7 +59,8 @@ class precision:
 
 class option:
     """context manager over the library's process-wide kernel-selection switches (vae_set_option: "flat_conv", "no_wino",
-    "no_wide"); the environment (VAEHIP_FLAT_CONV / VAEHIP_NO_WINO / VAEHIP_NO_WIDE) only gives their initial values"""
+    "no_wino4", "no_wide", and the count "wide_reserved_cus"); the environment (VAEHIP_FLAT_CONV / VAEHIP_NO_WINO / ...) only
+    gives their initial values"""
 
     def __init__(self, name: str, value: int = 1):
         self.name, self.value = name.encode(), int(value)
@@ -106,6 +107,7 @@ class LaunchProfiler:
 
 PROFILER: Optional[LaunchProfiler] = None
 WINO_EXECUTED = 16.0 / 36.0  # F(2x2,3x3) / F(3x3,2x2): 16 multiplications per 36 direct multiply-adds
+WINO4_EXECUTED = 36.0 / 144.0  # F(4x4,3x3): 36 per 144
 
 
 def _kernel_name(fn: str, a) -> str:
@@ -141,7 +143,8 @@ def _launch_igemm(a: IgemmArgs):
         lowres = a.M / 4.0 if a.g.mode == MODE_UP2X else float(a.M)
         _timed(name, 2.0 * lowres * a.N * a.K * 36, 2.0 * lowres * a.N * a.K * 9, "vae_igemm_rows", C.byref(a), _stream())
         return
-    _timed(name, base * taps, base * ex_taps * (WINO_EXECUTED if "wino" in name else 1.0), "vae_igemm_rows", C.byref(a), _stream())
+    frac = WINO4_EXECUTED if "wino4" in name else (WINO_EXECUTED if "wino" in name else 1.0)
+    _timed(name, base * taps, base * ex_taps * frac, "vae_igemm_rows", C.byref(a), _stream())
 
 
 def _launch_wgrad(a: WgradArgs):
