@@ -42,13 +42,12 @@ constexpr int FBN = 64;                  // output channels per workgroup
 constexpr int FSV = FPOS * FNTL * FBK;   // floats per V buffer (36,864 B)
 constexpr int FHW = 34, FHH = 18;        // halo of the tile
 constexpr int FHP = FHW * FHH;           // 612 pixels
-constexpr int FPL = 641;                 // floats per channel plane of the halo image (= 1 mod 32)
-constexpr int FSH = FBK * FPL;           // floats per halo buffer (20,512 B)
+constexpr int FSH = 1536 * 4;            // floats per halo buffer: 1536 slots of 16 B (24,576 B), see the kernel
 constexpr int FSS = 2 * 1024;            // GroupNorm scale / shift rows of the image (K <= 1024)
-constexpr int FMLD = 33;                 // epilogue image row (floats)
+constexpr int FMLD = 32;                 // epilogue image row (floats): writes are lane-contiguous per tile, reads per (position, tile): no padding needed
 constexpr int FSM = FPOS * FNTL * FMLD + 12 * 8 * 2 + 24 * 32 * 2;  // epilogue image + statistics scratch + GroupNorm-backward sums
 constexpr int FMAIN = 2 * FSV + 2 * FSH + FSS;
-constexpr int F_LDS = (FSM > FMAIN ? FSM : FMAIN) * 4;  // 158,976 B
+constexpr int F_LDS = (FSM > FMAIN ? FSM : FMAIN) * 4;  // 154,368 B
 static_assert(F_LDS <= 160 * 1024, "LDS");
 
 // U[pos][n][k] = (G g G^T)[pos] for g = W[n][.][.][k] (forward) or g = rot180(W[k][.][.][n]) (dgrad); layout [K/8][36][N][8]
@@ -116,8 +115,20 @@ __device__ __forceinline__ void at6(const float m[6], float y[4]) {
 template <int XF>
 __global__ __launch_bounds__(FNT, 3) void conv3_wino4_kernel(vae_igemm_args p, const float* __restrict__ U, int tiles_x, int tiles_y, int xcd_sp) {
   __shared__ __attribute__((aligned(16))) float wsm[F_LDS / 4];
-  float* const sV = wsm;            // [2][FSV]
-  float* const sH = wsm + 2 * FSV;  // [2][FSH]: the chunk's input halo, transformed, as channel planes
+  float* const sH = wsm;            // [2][FSH]: the chunk's input halo (first: the LDS-DMA base stays below 64 KB)
+  float* const sV = wsm + 2 * FSH;  // [2][FSV]
+#ifdef VAE_WINO4_TIMING  // debug build (tools/wino4_timing.py): shader-clock stamps of waves 0, 4, 8 (the three waves of SIMD 0) of workgroups 0..7 -> p.track
+  unsigned long long tE[10];  // entry, loop entry, loop exit, block 0: accumulators in LDS / outputs stored, block 1: the same, end; [8], [9]: 100 MHz clock
+  unsigned long long tS[8][4];  // steps 2..9: begin, after the first phase, after the second, after the barrier
+  const bool tw = (threadIdx.x & 255) == 0;
+#define WEDGE(k) do { if (tw) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tE[k] = __builtin_amdgcn_s_memtime(); } } while (0)
+#define WSTAMP(s, k) do { if (tw && (s) >= 2 && (s) < 10) { tS[(s) - 2][k] = __builtin_amdgcn_s_memtime(); } } while (0)
+  if (tw) tE[8] = __builtin_amdgcn_s_memrealtime();
+#else
+#define WEDGE(k) do { } while (0)
+#define WSTAMP(s, k) do { } while (0)
+#endif
+  WEDGE(0);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
@@ -139,22 +150,39 @@ __global__ __launch_bounds__(FNT, 3) void conv3_wino4_kernel(vae_igemm_args p, c
   const int y0 = ty * FTH, x0 = tx * FTW, n0 = tn * FBN;
   const int nsteps = p.K / FBK;
 
-  // ---- halo role: item i = (pixel hp of the 18 x 34 halo, channel quad hq); thread tid owns items tid and tid + 768 (< 1224) ----
+  // ---- the chunk's 18 x 34 input halo in LDS: pixel-major, 8 channels (32 B) per pixel, 32 B of padding behind every 4 pixels:
+  //          dword address of (pixel hp, channel c) = 8 (hp + (hp >> 2)) + c
+  // (4 tiles x 8 channels -- what a 32-lane group of the transform reads -- are then 32 different banks; without the padding all
+  // tiles would sit on the same 8).  In 16-byte slots: slot m = 2 (hp + (hp >> 2)) + quad; 1530 slots, rounded to 1536 = 24
+  // wave-instructions of LDS-DMA (buffer_load_dwordx4 ... lds: 64 lanes x 16 B land lane-linear at M0), TWO PER WAVE and step: the
+  // halo never passes through registers, no thread waits for it and nothing is stored by hand.  Lanes whose slot is padding or
+  // lies outside the image request an out-of-range offset: the DMA writes zeros (= the convolution's zero padding).
+  // XF != NONE (GroupNorm(+SiLU) fused into the staging) cannot use the DMA: those instantiations stage through registers (two
+  // steps ahead, as conv3_wino.hip) into the same image.
   const auto rsA = VAE_BUF_RSRC(p.A + (int64_t)b * g.Hs * g.Ws * g.Cs, (size_t)g.Hs * g.Ws * g.Cs * 4u);
-  unsigned hbase[2];
-  int hdst[2];
+  unsigned hoff[2];   // XF == NONE: source offsets of this lane's two slots; else: of the thread's two (pixel, quad) items
+  int hdst[2];        // XF != NONE: LDS dword of the item
   bool hin[2], hown[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int it = tid + j * FNT;
-    const int hp = it >> 1, hq = it & 1;
-    hown[j] = it < 2 * FHP;
+    int hp, hq;
+    if (XF == VAE_XF_NONE) {
+      const int m = (wave * 2 + j) * 64 + lane, grp = m / 10, r = m - grp * 10;
+      hp = 4 * grp + (r >> 1);
+      hq = r & 1;
+      hown[j] = r < 8 && hp < FHP;
+    } else {
+      const int it = tid + j * FNT;
+      hp = it >> 1;
+      hq = it & 1;
+      hown[j] = it < 2 * FHP;
+    }
     const int hy = y0 - 1 + hp / FHW, hx = x0 - 1 + hp % FHW;
     hin[j] = hown[j] && ((unsigned)hy < (unsigned)g.Hs) && ((unsigned)hx < (unsigned)g.Ws);
-    hbase[j] = hin[j] ? (unsigned)(((hy * g.Ws + hx) * g.Cs + hq * 4) * 4) : BUF_OOB;
-    hdst[j] = hq * 4 * FPL + hp;
+    hoff[j] = hin[j] ? (unsigned)(((hy * g.Ws + hx) * g.Cs + hq * 4) * 4) : BUF_OOB;
+    hdst[j] = 8 * (hp + (hp >> 2)) + 4 * hq;
   }
-  float* const sS = wsm + 2 * FSV + 2 * FSH;  // GroupNorm scale / shift rows of image b ([2][K])
+  float* const sS = wsm + 2 * FSH + 2 * FSV;  // GroupNorm scale / shift rows of image b ([2][K])
   if (XF != VAE_XF_NONE) {
     for (int i = tid; i < p.K; i += FNT) {
       sS[i] = p.scale[(int64_t)b * g.Cs + i];
@@ -162,92 +190,116 @@ __global__ __launch_bounds__(FNT, 3) void conv3_wino4_kernel(vae_igemm_args p, c
     }
     __syncthreads();
   }
+  // LDS-DMA of halo(step) into halo buffer `par` (XF == NONE).  Inline asm: hipcc must not see these loads -- with a visible
+  // LDS-DMA in flight it waits vmcnt(0) at the next use of ANY load, which would serialise the U-fragment pipeline below.  They
+  // are the OLDEST vector-memory operations of a step (6 fragment re-requests follow), so `s_waitcnt vmcnt(6)` in front of the
+  // step's barrier retires them; beyond the last chunk the last one is requested again (never read) so the count stays fixed.
+  const unsigned lds_h = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)sH) + (unsigned)wave * 2048u;
+  auto dma_halo = [&](int step, int par) {
+    const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(min(step, nsteps - 1) * FBK * 4));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds_h + (unsigned)par * (FSH * 4u) + (unsigned)j * 1024u);
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "s"(dst), "v"(hoff[j]), "s"(rsA), "s"(so) : "memory");
+    }
+  };
   struct Halo {
     f32x4 v[2];
   };
   Halo rh;
   rh.v[0] = rh.v[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto load_halo_into = [&](int step, Halo& h) {
+  auto load_halo_into = [&](int step, Halo& h) {  // XF != NONE
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const bool ok = hin[j] && step < nsteps;
-      h.v[j] = VAE_BUF_LOAD4(rsA, ok ? hbase[j] + (unsigned)(step * FBK * 4) : BUF_OOB);
+      h.v[j] = VAE_BUF_LOAD4(rsA, ok ? hoff[j] + (unsigned)(step * FBK * 4) : BUF_OOB);
     }
   };
-  auto store_halo_from = [&](float* dst, const Halo& h, int step) {
+  auto store_halo_from = [&](float* dst, const Halo& h, int step) {  // XF != NONE
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       if (!hown[j]) continue;
       f32x4 v = h.v[j];
-      if (XF != VAE_XF_NONE) {
-        const int c = min(step, nsteps - 1) * FBK + ((tid + j * FNT) & 1) * 4;
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(&sS[c]), sh = *reinterpret_cast<const f32x4*>(&sS[p.K + c]);
+      const int c = min(step, nsteps - 1) * FBK + ((tid + j * FNT) & 1) * 4;
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(&sS[c]), sh = *reinterpret_cast<const f32x4*>(&sS[p.K + c]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float u = v[e] * sc[e] + sh[e];
-          if (XF == VAE_XF_AFFINE_SILU) u = silu_f(u);
-          v[e] = (hin[j] && step < nsteps) ? u : 0.f;  // padding stays zero AFTER the transform
-        }
+      for (int e = 0; e < 4; ++e) {
+        float u = v[e] * sc[e] + sh[e];
+        if (XF == VAE_XF_AFFINE_SILU) u = silu_f(u);
+        v[e] = (hin[j] && step < nsteps) ? u : 0.f;  // padding stays zero AFTER the transform
       }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) dst[hdst[j] + e * FPL] = v[e];
+      *reinterpret_cast<f32x4*>(&dst[hdst[j]]) = v;
     }
   };
 
-  // ---- V role (all threads): tile vt = (vty, vtx), channel vc of the chunk, row pair rg (uniform per wave: tid >> 8) ----
-  const int vtx = tid & 7, vcl = (tid >> 3) & 3, vty = (tid >> 5) & 3, vch = (tid >> 7) & 1, rg = tid >> 8;
-  const int vsrc = (vch * 4 + vcl) * FPL + (4 * vty) * FHW + 4 * vtx;              // patch origin in the halo image
-  const int vdst = (vch * FNTL + vty * 8 + vtx) * 4 + vcl;                         // + pos * (2 * FNTL * 4)
-  auto write_v = [&](const float* sHc, float* dst) {
+  // ---- V role (all threads): channel vc of the chunk (fastest: a 32-lane group = 8 channels x 4 tile columns), tile (vty, vtx),
+  // row pair RG = tid >> 8 (uniform per wave: each wave group runs its own copy of the main loop).  The thread takes rows
+  // {1,2} (RG 0), {3,4} (RG 1) or {0,5} (RG 2) of B^T d -- they share their sub-expressions pairwise -- two patch columns at a
+  // time, then those two rows times B: 48 operations, 12 values written to the V image [36][2 k-halves][32 tiles][4].
+  const int vc = tid & 7, vtx = (tid >> 3) & 7, vty = (tid >> 6) & 3;
+  const int vsrc = 10 * ((4 * vty) * FHW + 4 * vtx) + vc;                   // dword of the patch origin (a multiple of 4 pixels)
+  const int vdst = ((vc >> 2) * FNTL + vty * 8 + vtx) * 4 + (vc & 3);       // + pos * (2 * FNTL * 4)
+#define W4_HOFF(i, j) (8 * (FHW * (i) + (j)) + 8 * ((FHW * (i) + (j)) >> 2))  /* (origin + x) >> 2 = origin / 4 + (x >> 2) */
+  // the patch values of columns 2k, 2k+1 the row pair needs: d[jj][i]
+  auto v_read = [&](const float* sHc, auto rg_c, auto k_c, float (&d)[2][6]) {
+    constexpr int RG = decltype(rg_c)::value, K2 = decltype(k_c)::value;
     const float* src = sHc + vsrc;
-    float tr[2][6];
-    int i0, i1;
-    if (rg == 0) {  // rows 1, 2 of B^T d
-      i0 = 1; i1 = 2;
 #pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        const float d1 = src[1 * FHW + j], d2 = src[2 * FHW + j], d3 = src[3 * FHW + j], d4 = src[4 * FHW + j];
-        const float a = fmaf(-4.f, d2, d4), bb = fmaf(-4.f, d1, d3);
+    for (int jj = 0; jj < 2; ++jj) {
+      constexpr int IA = RG == 2 ? 0 : 1, IB = RG == 2 ? 6 : 5;
+#pragma unroll
+      for (int i = IA; i < IB; ++i) d[jj][i] = src[W4_HOFF(i, 2 * K2 + jj)];
+    }
+  };
+  auto v_cols = [&](const float (&d)[2][6], auto rg_c, auto k_c, float (&tr)[2][6]) {
+    constexpr int RG = decltype(rg_c)::value, K2 = decltype(k_c)::value;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int j = 2 * K2 + jj;
+      if (RG == 0) {  // rows 1, 2 of B^T d
+        const float a = fmaf(-4.f, d[jj][2], d[jj][4]), bb = fmaf(-4.f, d[jj][1], d[jj][3]);
         tr[0][j] = a + bb;
         tr[1][j] = a - bb;
-      }
-    } else if (rg == 1) {  // rows 3, 4
-      i0 = 3; i1 = 4;
-#pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        const float d1 = src[1 * FHW + j], d2 = src[2 * FHW + j], d3 = src[3 * FHW + j], d4 = src[4 * FHW + j];
-        const float c = d4 - d2, e = d3 - d1;
+      } else if (RG == 1) {  // rows 3, 4
+        const float c = d[jj][4] - d[jj][2], e = d[jj][3] - d[jj][1];
         tr[0][j] = fmaf(2.f, e, c);
         tr[1][j] = fmaf(-2.f, e, c);
-      }
-    } else {  // rows 0, 5
-      i0 = 0; i1 = 5;
-#pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        const float d0 = src[j], d1 = src[1 * FHW + j], d2 = src[2 * FHW + j], d3 = src[3 * FHW + j], d4 = src[4 * FHW + j], d5 = src[5 * FHW + j];
-        tr[0][j] = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
-        tr[1][j] = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
+      } else {  // rows 0, 5
+        tr[0][j] = fmaf(4.f, d[jj][0], fmaf(-5.f, d[jj][2], d[jj][4]));
+        tr[1][j] = fmaf(4.f, d[jj][1], fmaf(-5.f, d[jj][3], d[jj][5]));
       }
     }
+  };
+  auto v_row = [&](float* dst, auto rg_c, auto q_c, const float (&tr)[2][6]) {  // row q of the pair: times B, into the V image
+    constexpr int RG = decltype(rg_c)::value, Q = decltype(q_c)::value;
+    constexpr int I = Q == 0 ? (RG == 0 ? 1 : (RG == 1 ? 3 : 0)) : (RG == 0 ? 2 : (RG == 1 ? 4 : 5));
     float v[6];
-    bt6(tr[0], v);
+    bt6(tr[Q], v);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) dst[(i0 * 6 + j) * (2 * FNTL * 4) + vdst] = v[j];
-    bt6(tr[1], v);
-#pragma unroll
-    for (int j = 0; j < 6; ++j) dst[(i1 * 6 + j) * (2 * FNTL * 4) + vdst] = v[j];
+    for (int j = 0; j < 6; ++j) dst[(I * 6 + j) * (2 * FNTL * 4) + vdst] = v[j];
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  auto write_v = [&](const float* sHc, float* dst, auto rg_c) {  // the whole transform in one go (prologue)
+    float d[2][6], tr[2][6];
+    v_read(sHc, rg_c, I0{}, d); v_cols(d, rg_c, I0{}, tr);
+    v_read(sHc, rg_c, I1{}, d); v_cols(d, rg_c, I1{}, tr);
+    v_read(sHc, rg_c, I2{}, d); v_cols(d, rg_c, I2{}, tr);
+    v_row(dst, rg_c, I0{}, tr);
+    v_row(dst, rg_c, I1{}, tr);
   };
 
   // ---- U fragments: B operand of (position, channel block nb) = U[step][pos][n0 + 32 nb + lr][4 lh .. 4 lh + 3] ----
   const auto rsU = VAE_BUF_RSRC(U, (size_t)nsteps * FPOS * p.N * 8 * 4u);
-  unsigned bvo[2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) bvo[q] = (unsigned)(((n0 + q * 32 + lr) * 8 + lh * 4) * 4);
+  const unsigned bvo = (unsigned)(((n0 + lr) * 8 + lh * 4) * 4);  // (+ 1024 B for the second channel block)
   const unsigned bpos = (unsigned)p.N * 32u;  // bytes per position of the U image
   f32x4 bq[6];
   auto load_b1 = [&](int step, int i) {
     const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(min(step, nsteps - 1) * FPOS + 3 * wave) * bpos);
-    bq[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsU, bvo[i & 1], so + (i >> 1) * bpos, 0));
+    bq[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsU, bvo + (i & 1) * 1024u, so + (i >> 1) * bpos, 0));
   };
 
   f32x16 acc[3][2];
@@ -258,10 +310,16 @@ __global__ __launch_bounds__(FNT, 3) void conv3_wino4_kernel(vae_igemm_args p, c
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[pi][nb][e] = 0.f;
 
-  // prologue: halo(0), halo(1) in LDS, V(0) from halo(0); halo(2) and the U fragments of step 0 in registers
+  // prologue: halo(0), halo(1) in LDS, V(0) from halo(0); the U fragments of step 0 in registers (XF != NONE: halo(2) too)
+  if (XF == VAE_XF_NONE) {
+    dma_halo(0, 0);
+    dma_halo(1, 1);
 #pragma unroll
-  for (int i = 0; i < 6; ++i) load_b1(0, i);
-  {
+    for (int i = 0; i < 6; ++i) load_b1(0, i);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  } else {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) load_b1(0, i);
     Halo h0, h1;
     load_halo_into(0, h0);
     load_halo_into(1, h1);
@@ -270,59 +328,100 @@ __global__ __launch_bounds__(FNT, 3) void conv3_wino4_kernel(vae_igemm_args p, c
     store_halo_from(sH + FSH, h1, 1);
   }
   __syncthreads();
-  write_v(sH, sV);
+  if (wave < 4) write_v(sH, sV, I0{});
+  else if (wave < 8) write_v(sH, sV, I1{});
+  else write_v(sH, sV, I2{});
   __syncthreads();
 
-  auto multiply = [&](const f32x4* a4, int s) {  // step s; requests step s+1's fragments as it goes
+  // One copy of the main loop per wave group (uniform per wave).  A wave's staging (LDS reads -> 48 operations -> LDS writes)
+  // measured alone is a chain of round trips as long as the step's MFMA work (tools/wino4_timing.py: 4400 cycles per step with
+  // the MFMAs removed, 5070 with the staging removed, 6700 with one after the other), so it is INTERLEAVED with the wave's own
+  // MFMAs: each group of 4 MFMAs (one position x one channel block, 256 cycles of the matrix pipe) is followed by the next
+  // slice of the transform, whose LDS latency then passes behind the following group:
+  //   DMA halo(s+2) | A(0), patch columns 0-1 requested | G(0,0) | columns 0-1 -> rows; columns 2-3 requested | G(0,1), A(1) |
+  //   columns 2-3; 4-5 requested | G(1,0) | columns 4-5; first row x B -> V(s+1) | G(1,1), A(2) | second row -> V(s+1) |
+  //   G(2,0) | G(2,1) | vmcnt(6): the DMA has landed | barrier
+  auto run = [&](auto rg_c) {
+    auto group = [&](const f32x4& a, int s, auto i_c) {  // 4 MFMAs of fragment i = 2 pi + nb, then its re-request for step s+1
+      constexpr int I = decltype(i_c)::value;
+#if !defined(VAE_W4_SKIP) || VAE_W4_SKIP != 1  // (diagnostic builds: 1 = no MFMAs, 2 = no staging)
 #pragma unroll
-    for (int pi = 0; pi < 3; ++pi)
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[pi][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[pi][e], bq[pi * 2 + nb][e], acc[pi][nb], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        load_b1(s + 1, pi * 2 + nb);
+      for (int e = 0; e < 4; ++e) acc[I >> 1][I & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], bq[I][e], acc[I >> 1][I & 1], 0, 0, 0);
+#else
+      acc[I >> 1][I & 1][0] += a[0] * bq[I][0];
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      load_b1(s + 1, I);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto step = [&](int s, int par) {
+      const float* cV = sV + par * FSV;
+      const float* cH = sH + (par ^ 1) * FSH;   // halo(s+1)
+      float* nV = sV + (par ^ 1) * FSV;         // V(s+1): nobody reads that buffer now
+      auto read_a = [&](int pi) { return *reinterpret_cast<const f32x4*>(&cV[(((3 * wave + pi) * 2 + lh) * FNTL + lr) * 4]); };
+      f32x4 a0, a1, a2;
+      float d[2][6], tr[2][6];
+      WSTAMP(s, 0);
+      if (XF == VAE_XF_NONE) dma_halo(s + 2, par);  // over halo(s), which V(s) was made from
+      a0 = read_a(0);
+#if !defined(VAE_W4_SKIP) || VAE_W4_SKIP != 2
+      v_read(cH, rg_c, I0{}, d);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      group(a0, s, I0{});
+#if !defined(VAE_W4_SKIP) || VAE_W4_SKIP != 2
+      v_cols(d, rg_c, I0{}, tr);
+      v_read(cH, rg_c, I1{}, d);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      group(a0, s, I1{});
+      a1 = read_a(1);
+#if !defined(VAE_W4_SKIP) || VAE_W4_SKIP != 2
+      v_cols(d, rg_c, I1{}, tr);
+      v_read(cH, rg_c, I2{}, d);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      WSTAMP(s, 1);
+      group(a1, s, I2{});
+#if !defined(VAE_W4_SKIP) || VAE_W4_SKIP != 2
+      v_cols(d, rg_c, I2{}, tr);
+      v_row(nV, rg_c, I0{}, tr);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      group(a1, s, std::integral_constant<int, 3>{});
+      a2 = read_a(2);
+#if !defined(VAE_W4_SKIP) || VAE_W4_SKIP != 2
+      v_row(nV, rg_c, I1{}, tr);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      WSTAMP(s, 2);
+      group(a2, s, std::integral_constant<int, 4>{});
+      if (XF != VAE_XF_NONE) {
+        store_halo_from(sH + par * FSH, rh, s + 2);  // halo(s+2) over halo(s)
+        load_halo_into(s + 3, rh);
         __builtin_amdgcn_sched_barrier(0);
       }
-  };
-  auto stage_next = [&](int s, int par) {
-    if (s + 1 < nsteps) write_v(sH + (par ^ 1) * FSH, sV + (par ^ 1) * FSV);  // V(s+1): nobody reads that buffer now
-    store_halo_from(sH + par * FSH, rh, s + 2);                                // halo(s+2) over halo(s)
-    load_halo_into(s + 3, rh);
-  };
-  auto step = [&](int s, int par, auto first_c) {
-    constexpr bool STAGE_FIRST = decltype(first_c)::value;
-    const float* cV = sV + par * FSV;
-    f32x4 a4[3];
-    auto read_a = [&]() {
-#pragma unroll
-      for (int pi = 0; pi < 3; ++pi) a4[pi] = *reinterpret_cast<const f32x4*>(&cV[(((3 * wave + pi) * 2 + lh) * FNTL + lr) * 4]);
+      group(a2, s, std::integral_constant<int, 5>{});
+      if (XF == VAE_XF_NONE) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // this step's DMA (older than the 6 re-requests) has landed
+      __syncthreads();
+      WSTAMP(s, 3);
     };
-    if (STAGE_FIRST) {
-      stage_next(s, par);
-      read_a();
-      __builtin_amdgcn_sched_barrier(0);
-      multiply(a4, s);
-      __builtin_amdgcn_sched_barrier(0);
-    } else {
-      read_a();
-      multiply(a4, s);
-      __builtin_amdgcn_sched_barrier(0);
-      stage_next(s, par);
-    }
-    __syncthreads();
-  };
-  auto run = [&](auto first_c) {
     int s = 0;
+#pragma unroll 1
     for (; s + 1 < nsteps; s += 2) {
-      step(s, 0, first_c);
-      step(s + 1, 1, first_c);
+      step(s, 0);
+      step(s + 1, 1);
     }
-    if (s < nsteps) step(s, 0, first_c);
+    if (s < nsteps) step(s, 0);
   };
-  if (wave >= 4 && wave < 8) run(std::false_type{});  // uniform per wave: the middle wave of every SIMD multiplies first
-  else run(std::true_type{});
+  WEDGE(1);
+  if (wave < 4) run(I0{});
+  else if (wave < 8) run(I1{});
+  else run(I2{});
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (a DMA of the last steps may still be writing the buffers the epilogue overlays)
+  __syncthreads();
 
+  WEDGE(2);
   // ---- epilogue: per 32-channel block, M through LDS, then Y = A^T M A ----
   float* const sM = wsm;  // [36][32 tiles][FMLD], over the V / halo buffers (the last step's barrier has passed)
   const size_t obytes = (size_t)g.Ho * g.Wo * p.ldc * 4u;
@@ -347,6 +446,7 @@ __global__ __launch_bounds__(FNT, 3) void conv3_wino4_kernel(vae_igemm_args p, c
       }
     }
     __syncthreads();
+    WEDGE(3 + 2 * nb);
     const int co = tid & 31, col = n0 + nb * 32 + co;
     const float bv = p.bias ? p.bias[col] : 0.f;
     float gpv = 0.f, gs1 = 0.f, gs2 = 0.f;  // GroupNorm statistics of this thread's outputs of channel `col`: shifted sums
@@ -363,21 +463,23 @@ __global__ __launch_bounds__(FNT, 3) void conv3_wino4_kernel(vae_igemm_args p, c
     for (int rnd = 0; rnd < nrnd; ++rnd) {
       const int tile = (tid >> 5) + 24 * rnd;
       const int oy = y0 + 4 * (tile >> 3), ox = x0 + 4 * (tile & 7);
+      // per-lane offset of the tile's first output + a workgroup-uniform (row, column) part in a scalar register: no address
+      // arithmetic on the vector pipe per access
       const unsigned obase = (unsigned)(((oy * g.Wo + ox) * p.ldc + col) * 4);
       const unsigned rstep = (unsigned)(g.Wo * p.ldc * 4), cstep = (unsigned)(p.ldc * 4);
       float rres[16];
       if (p.res) {  // uniform: requested before the LDS reads below
 #pragma unroll
         for (int q = 0; q < 16; ++q)
-          rres[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, obase + (q >> 2) * rstep + (q & 3) * cstep, 0, 0));
+          rres[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, obase, (q >> 2) * rstep + (q & 3) * cstep, 0));
       }
       float xin[16];
       if (gnb) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-          const unsigned eo = obase + (q >> 2) * rstep + (q & 3) * cstep;
-          xin[q] = p.gnb_x_bf16 ? __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rsX, eo >> 1, 0, 0) << 16)
-                                : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX, eo, 0, 0));
+          const unsigned so = (q >> 2) * rstep + (q & 3) * cstep;
+          xin[q] = p.gnb_x_bf16 ? __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rsX, obase >> 1, so >> 1, 0) << 16)
+                                : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX, obase, so, 0));
         }
       }
       float h[4][6];  // A^T M: per column j of M the 4 output rows
@@ -399,7 +501,7 @@ __global__ __launch_bounds__(FNT, 3) void conv3_wino4_kernel(vae_igemm_args p, c
           const int q = a * 4 + bb;
           float v = y[bb] + bv;
           if (p.res) v += rres[q];
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, obase + a * rstep + bb * cstep, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, obase, a * rstep + bb * cstep, 0);
           if (rnd == 0 && q == 0) gpv = v;
           const float dv = v - gpv;
           gs1 += dv;
@@ -414,6 +516,7 @@ __global__ __launch_bounds__(FNT, 3) void conv3_wino4_kernel(vae_igemm_args p, c
         }
       }
     }
+    WEDGE(4 + 2 * nb);
     if (gnb) {
       redb[((tid >> 5) * 32 + co) * 2] = bs1;
       redb[((tid >> 5) * 32 + co) * 2 + 1] = bs2;
@@ -454,6 +557,20 @@ __global__ __launch_bounds__(FNT, 3) void conv3_wino4_kernel(vae_igemm_args p, c
     }
     __syncthreads();  // (the next block's accumulators overwrite the image and the scratch)
   }
+#ifdef VAE_WINO4_TIMING
+  WEDGE(7);
+  if (tw) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tE[9] = __builtin_amdgcn_s_memrealtime();
+    if (p.track && blockIdx.x < 8) {  // [workgroup][wave group][10 + 32] uint64
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(p.track) + (blockIdx.x * 3 + (threadIdx.x >> 8)) * 42;
+#pragma unroll
+      for (int i = 0; i < 10; ++i) o[i] = tE[i];
+#pragma unroll
+      for (int i = 0; i < 32; ++i) o[10 + i] = tS[i >> 2][i & 3];
+    }
+  }
+#endif
 }
 
 }  // namespace
@@ -463,7 +580,10 @@ bool conv3_wino4_eligible(const vae_igemm_args& a) {
   const vae_conv_geom& g = a.g;
   if (a.prec != VAE_PREC_F32 || a.A16 != nullptr || a.batch != 1 || a.alpha != 1.0f) return false;
   if (g.taps != 9 || g.stride != 1 || g.pad_t != 1 || g.pad_l != 1) return false;
-  if (a.tapmask != 0 || a.a_step > 1 || a.c_step > 1 || a.out_bf16 || a.track != nullptr) return false;
+  if (a.tapmask != 0 || a.a_step > 1 || a.c_step > 1 || a.out_bf16) return false;
+#ifndef VAE_WINO4_TIMING  // (the instrumented build writes its stamps through `track`)
+  if (a.track != nullptr) return false;
+#endif
   if (!(g.mode == VAE_MODE_FWD || g.mode == VAE_MODE_DGRAD) || g.Ho != g.Hs || g.Wo != g.Ws) return false;
   if (g.mode == VAE_MODE_DGRAD && a.xf != VAE_XF_NONE) return false;
   if (g.Ho % FTH != 0 || g.Wo % FTW != 0 || a.K % FBK != 0 || a.K < 64 || a.K > 1024 || a.N % FBN != 0 || g.Cs < a.K) return false;
