@@ -38,7 +38,8 @@ int vae_sizeof_args(int32_t which);
 /* Process-wide kernel-selection switches (no launch path reads the environment): "flat_conv" (flat implicit-GEMM kernels
  * everywhere: the second algorithm of the two-algorithm tests), "no_wino" (fp32: the direct halo-tile kernels instead of the
  * Winograd ones: the parity reference), "no_wino4" (fp32: F(2x2,3x3) also on the layers F(4x4,3x3) would serve; a Wu image
- * must be built and consumed under the same value: vae_wino_weight_floats / vae_wino_weights / vae_igemm_rows all follow it), "no_wide" (bf16: the 128-pixel halo-tile kernel instead of the wide-tile one).
+ * must be built and consumed under the same value: vae_wino_weight_floats / vae_wino_weights / vae_igemm_rows all follow it),
+ * "no_thin_mfma" (bf16: the <= 4-channel-side layers stay on the VALU kernels), "no_wide" (bf16: the 128-pixel halo-tile kernel instead of the wide-tile one).
  * One option is a count, not a switch: "wide_reserved_cus" (0..128, default 0): the persistent bf16 wide-tile kernel launches
  * 256 - n workgroups instead of one per CU, leaving n CUs to RCCL's workgroups while gradient buckets are in flight
  * (data-parallel runs: reference src/train.py:204-211); any grid covers all tiles, so results do not depend on it.

@@ -221,9 +221,27 @@ def test_narrow_side_kernels_with_bf16_wide_side(act16):
     dy16 = torch.randn(B, H, W, 128, generator=gen).cuda().bfloat16()
     gw = [torch.empty(128, 3, 3, 3, device="cuda").permute(0, 3, 1, 2) for _ in range(2)]
     gb = [torch.empty(128, device="cuda") for _ in range(2)]
-    ops.conv_wgrad(dy16, x4, "c3", gw[0], gb[0])
-    ops.conv_wgrad(dy16.float(), x4, "c3", gw[1], gb[1])
+    with ops.option("no_thin_mfma"):  # the VALU kernel (skinny.hip) on both storages: bitwise
+        ops.conv_wgrad(dy16, x4, "c3", gw[0], gb[0])
+        ops.conv_wgrad(dy16.float(), x4, "c3", gw[1], gb[1])
     assert torch.equal(gw[0], gw[1]) and torch.equal(gb[0], gb[1])
+    # round 4: with the wide side stored as bf16 the launch runs on the matrix pipe (csrc/wgrad_thin_bf16.hip): bf16 products of
+    # the bf16 gradient with the image ROUNDED to bf16, fp32 accumulation -- against that arithmetic in float64
+    gwm, gbm = torch.empty(128, 3, 3, 3, device="cuda").permute(0, 3, 1, 2), torch.empty(128, device="cuda")
+    prof = ops.PROFILER = ops.LaunchProfiler()
+    try:
+        ops.conv_wgrad(dy16, x4, "c3", gwm, gbm)
+    finally:
+        ops.PROFILER = None
+    assert _names(prof) == ["wgrad_thin_bf16_kernel<true,0>"], _names(prof)
+    xr = x4[..., :3].bfloat16().double().cpu().permute(0, 3, 1, 2)
+    wz = torch.zeros(128, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xr, wz, None, 1, 1).backward(dy16.double().cpu().permute(0, 3, 1, 2))
+    assert _rel(gwm.cpu(), wz.grad) < 2e-6 and _rel(gbm, dy16.double().sum(dim=(0, 1, 2))) < 2e-6
+    assert _rel(gwm, gw[1]) < 1e-2  # (the fp32 kernel on the unrounded image: bf16 rounding of the narrow side only)
+    gwm2, gbm2 = torch.empty_like(gwm), torch.empty_like(gbm)
+    ops.conv_wgrad(dy16, x4, "c3", gwm2, gbm2)
+    assert torch.equal(gwm2, gwm) and torch.equal(gbm2, gbm)  # deterministic
     # conv_out: GroupNorm+SiLU fused on a bf16 input, 3 fp32 outputs; dgrad back to a bf16 128-channel gradient; wgrad
     h16 = _nhwc(torch.randn(B, 128, H, W, generator=gen) + 0.2).bfloat16()
     gamma, beta = (1 + 0.3 * torch.randn(128, generator=gen)).cuda(), (0.2 * torch.randn(128, generator=gen)).cuda()
@@ -242,9 +260,23 @@ def test_narrow_side_kernels_with_bf16_wide_side(act16):
     assert r16.dtype == torch.float32 and torch.equal(r16, r32)
     assert g16.dtype == torch.bfloat16 and torch.equal(g16, g32.bfloat16())
     gw = [torch.empty(3, 3, 3, 128, device="cuda").permute(0, 3, 1, 2) for _ in range(2)]
-    ops.conv_wgrad(dr, h16, "c3", gw[0], None, xf=ops.XF_AFFINE_SILU, stats=st)
-    ops.conv_wgrad(dr, h16.float(), "c3", gw[1], None, xf=ops.XF_AFFINE_SILU, stats=st)
+    with ops.option("no_thin_mfma"):
+        ops.conv_wgrad(dr, h16, "c3", gw[0], None, xf=ops.XF_AFFINE_SILU, stats=st)
+        ops.conv_wgrad(dr, h16.float(), "c3", gw[1], None, xf=ops.XF_AFFINE_SILU, stats=st)
     assert torch.equal(gw[0], gw[1])
+    # the matrix-pipe kernel: silu(gn(x)) in fp32 from the bf16 tensor, rounded once to bf16; dY rounded to bf16; fp32 accumulation
+    gwm, gbm = torch.empty(3, 3, 3, 128, device="cuda").permute(0, 3, 1, 2), torch.empty(3, device="cuda")
+    prof = ops.PROFILER = ops.LaunchProfiler()
+    try:
+        ops.conv_wgrad(dr, h16, "c3", gwm, gbm, xf=ops.XF_AFFINE_SILU, stats=st)
+    finally:
+        ops.PROFILER = None
+    assert _names(prof) == ["wgrad_thin_bf16_kernel<false,2>"], _names(prof)
+    act = ops.gn_apply(h16, st, ops.XF_AFFINE_SILU).bfloat16().double().cpu().permute(0, 3, 1, 2)  # (the same fp32 transform, rounded)
+    wz = torch.zeros(3, 128, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(act, wz, None, 1, 1).backward(dr.bfloat16().double().cpu().permute(0, 3, 1, 2))
+    assert _rel(gwm.cpu(), wz.grad) < 2e-5 and _rel(gbm, dr.double().sum(dim=(0, 1, 2))) < 2e-6
+    assert _rel(gwm, gw[1]) < 1e-2
     # decoder.conv_in (4 -> 512): fp32 latents in, bf16 out; its dgrad: a bf16 512-channel gradient -> 4 fp32 channels
     z = _nhwc(torch.randn(B, 4, 8, 8, generator=gen))
     w_z = act16(_to_dev_ohwi(torch.randn(512, 4, 3, 3, generator=gen) / 6))

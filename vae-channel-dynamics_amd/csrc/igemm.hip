@@ -65,6 +65,7 @@ int launch_conv_smalln(const vae_igemm_args& a, hipStream_t st);
 int wgrad_smallk_kind(const vae_wgrad_args& a);
 int wgrad_smallk_tiles(const vae_wgrad_args& a);
 int launch_wgrad_smallk(const vae_wgrad_args& a, hipStream_t st);
+bool wgrad_smallk_on_mfma(const vae_wgrad_args& a);  // bf16 mode: the launch runs on wgrad_thin_bf16.hip instead
 int launch_rows_bf16(const vae_igemm_args& a, bool bkm, hipStream_t st);   // igemm_bf16.hip (vectorised shapes only)
 int launch_wgrad_bf16(const vae_wgrad_args& a, hipStream_t st);
 
@@ -970,6 +971,7 @@ extern "C" int vae_wgrad_kernel_name(const vae_wgrad_args* ap, char* buf, int32_
   if (wgrad_is_phase(a) && a.prec == VAE_PREC_BF16)
     snprintf(buf, n, "wgrad3_tile_bf16_kernel<false,%d,%s,%s>", a.xf, tf[a.X16 != nullptr], tf[a.dY16 != nullptr]);
   else if (wgrad_is_phase(a)) snprintf(buf, n, "wgrad3_tile_kernel<%s,%d>", tf[a.g.mode == VAE_MODE_UP2X], a.xf);
+  else if (wgrad_smallk_kind(a) && wgrad_smallk_on_mfma(a)) snprintf(buf, n, "wgrad_thin_bf16_kernel<%s,%d>", tf[wgrad_smallk_kind(a) == 1], a.xf);
   else if (wgrad_smallk_kind(a)) snprintf(buf, n, "wgrad_smallk_kernel<%s,%d>", tf[wgrad_smallk_kind(a) == 1], a.xf);
   else if (wgrad_use_tile_bf16(a)) snprintf(buf, n, "wgrad3_tile_bf16_kernel<%s,%d,%s,%s>", tf[a.g.mode == VAE_MODE_UP2X], a.xf, tf[a.X16 != nullptr], tf[a.dY16 != nullptr]);
   else if (wgrad_use_tile(a)) snprintf(buf, n, "wgrad3_tile_kernel<%s,%d>", tf[a.g.mode == VAE_MODE_UP2X], a.xf);

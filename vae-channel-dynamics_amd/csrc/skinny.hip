@@ -224,6 +224,10 @@ int wgrad_smallk_kind(const vae_wgrad_args& a) {
   return 0;
 }
 int wgrad_smallk_tiles(const vae_wgrad_args& a) { return (int)(((int64_t)a.g.B * a.g.Ho * a.g.Wo + TP - 1) / TP); }
+bool wgrad_thin_bf16_eligible(const vae_wgrad_args& a, int kind);  // wgrad_thin_bf16.hip: the same launches on the bf16 matrix pipe
+int launch_wgrad_thin_bf16(const vae_wgrad_args& a, int kind, const vae_conv_geom& gs, int ntiles, hipStream_t st);
+bool wgrad_smallk_on_mfma(const vae_wgrad_args& a) { return wgrad_thin_bf16_eligible(a, wgrad_smallk_kind(a)) && !vae_opt().no_thin_mfma; }
+
 int launch_wgrad_smallk(const vae_wgrad_args& a, hipStream_t st) {
   const int kind = wgrad_smallk_kind(a);
   const int ntiles = wgrad_smallk_tiles(a);
@@ -232,6 +236,7 @@ int launch_wgrad_smallk(const vae_wgrad_args& a, hipStream_t st) {
     gs.mode = VAE_MODE_DGRAD;
     gs.Cs = a.ldy;
   }
+  if (wgrad_smallk_on_mfma(a)) return launch_wgrad_thin_bf16(a, kind, gs, ntiles, st);  // bf16 mode, wide side stored as bf16
   const int wide = kind == 1 ? a.M : a.N;
   dim3 grid((unsigned)a.nsplit, (unsigned)((wide + 127) / 128));
 #define WSK(SX, XFV) hipLaunchKernelGGL((wgrad_smallk_kernel<SX, XFV>), grid, dim3(NT), 0, st, a, gs, ntiles)
