@@ -210,13 +210,28 @@ def test_narrow_side_kernels_with_bf16_wide_side(act16):
     tb16, tb32 = ops.conv_track_buffer(B * H * W, 128, "cuda"), ops.conv_track_buffer(B * H * W, 128, "cuda")
     prof = ops.PROFILER = ops.LaunchProfiler()
     try:
-        y16 = ops.conv_fwd(x4, w_in, b_in, "c3", track=tb16)
-        y32 = ops.conv_fwd(x4, w_in, b_in, "c3", track=tb32, out_dtype=torch.float32)
+        with ops.option("no_thin_mfma"):  # the VALU kernel on both storages of the output: bitwise
+            y16 = ops.conv_fwd(x4, w_in, b_in, "c3", track=tb16)
+            y32 = ops.conv_fwd(x4, w_in, b_in, "c3", track=tb32, out_dtype=torch.float32)
     finally:
         ops.PROFILER = None
     assert _names(prof) == ["conv_smallk_kernel"] * 2 and y16.dtype == torch.bfloat16 and torch.equal(y16, y32.bfloat16())
     t16 = ops.track_final(tb16, B * H * W)
     assert _rel(t16, y16.float().abs().mean(dim=(0, 1, 2))) < 1e-5 and _rel(t16, ops.track_final(tb32, B * H * W)) < 5e-3
+    # round 4: a bf16 output runs on the matrix pipe (csrc/conv_thin_bf16.hip): image and weights rounded to bf16, fp32
+    # accumulation, bias in fp32, one rounding of the result -- against that arithmetic in float64; tracker from the stored values
+    tbm = ops.conv_track_buffer(B * H * W, 128, "cuda")
+    prof = ops.PROFILER = ops.LaunchProfiler()
+    try:
+        ym = ops.conv_fwd(x4, w_in, b_in, "c3", track=tbm)
+    finally:
+        ops.PROFILER = None
+    assert _names(prof) == ["conv_thin_bf16_kernel"] and ym.dtype == torch.bfloat16
+    w_r = w_in.bfloat16().double().cpu()
+    ref = F.conv2d(x4[..., :3].bfloat16().double().cpu().permute(0, 3, 1, 2), w_r, b_in.double().cpu(), 1, 1).permute(0, 2, 3, 1)
+    assert _rel(ym, ref) < 6e-3 and float(((ym.double().cpu() - ref).abs() > 2.0 ** -7 * ref.abs() + 1e-6).float().mean()) == 0.0  # <= 1 bf16 ulp
+    assert _rel(ops.track_final(tbm, B * H * W), ym.float().abs().mean(dim=(0, 1, 2))) < 1e-5
+    assert torch.equal(ops.conv_fwd(x4, w_in, b_in, "c3"), ym)  # deterministic, with and without the tracker
     # its weight gradient: dY wide (bf16), X narrow (fp32)
     dy16 = torch.randn(B, H, W, 128, generator=gen).cuda().bfloat16()
     gw = [torch.empty(128, 3, 3, 3, device="cuda").permute(0, 3, 1, 2) for _ in range(2)]
@@ -249,16 +264,29 @@ def test_narrow_side_kernels_with_bf16_wide_side(act16):
     w_out = act16(_to_dev_ohwi(torch.randn(3, 128, 3, 3, generator=gen) / 30))
     prof = ops.PROFILER = ops.LaunchProfiler()
     try:
-        r16 = ops.conv_fwd(h16, w_out, None, "c3", xf=ops.XF_AFFINE_SILU, stats=st)
-        r32 = ops.conv_fwd(h16.float(), w_out, None, "c3", xf=ops.XF_AFFINE_SILU, stats=st)
-        dr = torch.randn(B, H, W, 3, generator=gen).cuda()
-        g16 = ops.conv_dgrad(dr, w_out, "c3", (H, W))
-        g32 = ops.conv_dgrad(dr, w_out, "c3", (H, W), out_dtype=torch.float32)
+        with ops.option("no_thin_mfma"):
+            r16 = ops.conv_fwd(h16, w_out, None, "c3", xf=ops.XF_AFFINE_SILU, stats=st)
+            r32 = ops.conv_fwd(h16.float(), w_out, None, "c3", xf=ops.XF_AFFINE_SILU, stats=st)
+            dr = torch.randn(B, H, W, 3, generator=gen).cuda()
+            g16 = ops.conv_dgrad(dr, w_out, "c3", (H, W))
+            g32 = ops.conv_dgrad(dr, w_out, "c3", (H, W), out_dtype=torch.float32)
     finally:
         ops.PROFILER = None
     assert _names(prof) == ["conv_smalln_kernel<2>"] * 2 + ["conv_smallk_kernel"] * 2, _names(prof)
     assert r16.dtype == torch.float32 and torch.equal(r16, r32)
     assert g16.dtype == torch.bfloat16 and torch.equal(g16, g32.bfloat16())
+    # conv_out's dgrad with a bf16 result: the matrix-pipe kernel (3 -> 128 channels is a <= 4-channel contraction)
+    prof = ops.PROFILER = ops.LaunchProfiler()
+    try:
+        gm = ops.conv_dgrad(dr, w_out, "c3", (H, W))
+    finally:
+        ops.PROFILER = None
+    assert _names(prof) == ["conv_thin_bf16_kernel"] and gm.dtype == torch.bfloat16
+    drr = dr.bfloat16().double().cpu().permute(0, 3, 1, 2).requires_grad_(False)
+    hz = torch.zeros(B, 128, H, W, dtype=torch.float64, requires_grad=True)
+    F.conv2d(hz, w_out.bfloat16().double().cpu(), None, 1, 1).backward(drr)
+    refg = hz.grad.permute(0, 2, 3, 1)
+    assert _rel(gm, refg) < 6e-3 and float(((gm.double().cpu() - refg).abs() > 2.0 ** -7 * refg.abs() + 1e-6).float().mean()) == 0.0
     gw = [torch.empty(3, 3, 3, 128, device="cuda").permute(0, 3, 1, 2) for _ in range(2)]
     with ops.option("no_thin_mfma"):
         ops.conv_wgrad(dr, h16, "c3", gw[0], None, xf=ops.XF_AFFINE_SILU, stats=st)
@@ -280,8 +308,12 @@ def test_narrow_side_kernels_with_bf16_wide_side(act16):
     # decoder.conv_in (4 -> 512): fp32 latents in, bf16 out; its dgrad: a bf16 512-channel gradient -> 4 fp32 channels
     z = _nhwc(torch.randn(B, 4, 8, 8, generator=gen))
     w_z = act16(_to_dev_ohwi(torch.randn(512, 4, 3, 3, generator=gen) / 6))
-    h = ops.conv_fwd(z, w_z, None, "c3")
-    assert h.dtype == torch.bfloat16 and torch.equal(h, ops.conv_fwd(z, w_z, None, "c3", out_dtype=torch.float32).bfloat16())
+    with ops.option("no_thin_mfma"):
+        h = ops.conv_fwd(z, w_z, None, "c3")
+        assert h.dtype == torch.bfloat16 and torch.equal(h, ops.conv_fwd(z, w_z, None, "c3", out_dtype=torch.float32).bfloat16())
+    hm = ops.conv_fwd(z, w_z, None, "c3")  # (4 -> 512 at 8 x 8: one 128-pixel tile, four channel blocks on the matrix-pipe kernel)
+    refz = F.conv2d(z.bfloat16().double().cpu().permute(0, 3, 1, 2), w_z.bfloat16().double().cpu(), None, 1, 1).permute(0, 2, 3, 1)
+    assert hm.dtype == torch.bfloat16 and _rel(hm, refz) < 6e-3
     dh16 = torch.randn(B, 8, 8, 512, generator=gen).cuda().bfloat16()
     dz = ops.conv_dgrad(dh16, w_z, "c3", (8, 8))
     assert dz.dtype == torch.float32 and torch.equal(dz, ops.conv_dgrad(dh16.float(), w_z, "c3", (8, 8)))

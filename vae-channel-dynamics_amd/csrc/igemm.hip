@@ -34,6 +34,8 @@ bool conv3_upwino_eligible(const vae_igemm_args& a);                    // conv3
 int launch_upwino_weights(const vae_igemm_args& a, float* U, hipStream_t st);
 int launch_conv3_upwino(const vae_igemm_args& a, const float* U, hipStream_t st);
 int conv3_wino_nb();
+bool conv_thin_bf16_eligible(const vae_igemm_args& a);                  // conv_thin_bf16.hip (bf16: <= 4-channel contraction on the matrix pipe)
+int launch_conv_thin_bf16(const vae_igemm_args& a, hipStream_t st);
 bool conv3_wino4_eligible(const vae_igemm_args& a);                     // conv3_wino4.hip (fp32 Winograd F(4x4,3x3))
 int launch_wino4_weights(const vae_igemm_args& a, float* U, hipStream_t st);
 int launch_conv3_wino4(const vae_igemm_args& a, const float* U, hipStream_t st);
@@ -824,6 +826,7 @@ extern "C" int vae_bf16_grad_image_ok(const vae_conv_geom* gp, int32_t Cout, int
   return wgrad_use_tile_bf16(w) ? 1 : 0;
 }
 
+static bool rows_thin_mfma(const vae_igemm_args& a) { return conv_thin_bf16_eligible(a) && !vae_opt().no_thin_mfma; }
 static bool rows_is_phase(const vae_igemm_args& a) { return a.tapmask != 0 || a.a_step > 1 || a.c_step > 1; }
 static bool rows_wino(const vae_igemm_args& a) {
   const bool bkm = rows_bkm(a);
@@ -942,6 +945,8 @@ extern "C" int vae_igemm_kernel_name(const vae_igemm_args* ap, char* buf, int32_
     snprintf(buf, n, "conv3_tile_bf16_kernel<%s,%s,%d,false>", tf[a.g.mode == VAE_MODE_DGRAD], tf[a.g.mode == VAE_MODE_UP2X], a.xf);
   else if (rows_is_phase(a))
     snprintf(buf, n, "conv3_tile_kernel<%s,%s,%s,%d>", tf[bkm], tf[a.g.mode == VAE_MODE_DGRAD], tf[a.g.mode == VAE_MODE_UP2X], a.xf);
+  else if (conv_smallk_eligible(a) && a.A16 == nullptr && rows_thin_mfma(a))
+    snprintf(buf, n, "conv_thin_bf16_kernel");
   else if (conv_smallk_eligible(a))
     snprintf(buf, n, "conv_smallk_kernel");
   else if (conv_smalln_eligible(a))
@@ -1035,6 +1040,11 @@ extern "C" int vae_igemm_rows(const vae_igemm_args* ap, void* stream) {
     VAE_CHECK(a.A16 == nullptr, "igemm_rows: a sub-sampled view of an operand image needs the wide-tile kernel (vae_conv_phase_ok)");
     if (int rc2 = (a.prec == VAE_PREC_BF16) ? launch_conv3_tile_bf16(a, bkm, st) : launch_conv3_tile(a, bkm, st)) return rc2;
     VAE_LAUNCH_CHECK("conv3_tile");
+    return VAE_OK;
+  }
+  if (a.A16 == nullptr && conv_smallk_eligible(a) && rows_thin_mfma(a)) {  // bf16 mode, bf16 output: the same launch on the matrix pipe
+    if (int rc2 = launch_conv_thin_bf16(a, st)) return rc2;
+    VAE_LAUNCH_CHECK("conv_thin_bf16");
     return VAE_OK;
   }
   if (a.A16 == nullptr && conv_smallk_eligible(a)) {
