@@ -275,6 +275,18 @@ def test_narrow_side_kernels_with_bf16_wide_side(act16):
     assert _names(prof) == ["conv_smalln_kernel<2>"] * 2 + ["conv_smallk_kernel"] * 2, _names(prof)
     assert r16.dtype == torch.float32 and torch.equal(r16, r32)
     assert g16.dtype == torch.bfloat16 and torch.equal(g16, g32.bfloat16())
+    # conv_out's forward on a bf16 input: the matrix-pipe kernel (fp32 GroupNorm+SiLU per halo element, rounded once; bf16 weights)
+    prof = ops.PROFILER = ops.LaunchProfiler()
+    try:
+        rm = ops.conv_fwd(h16, w_out, None, "c3", xf=ops.XF_AFFINE_SILU, stats=st)
+        rmb = ops.conv_fwd(h16, w_out, torch.tensor([0.5, -1.0, 2.0], device="cuda"), "c3", xf=ops.XF_AFFINE_SILU, stats=st)
+    finally:
+        ops.PROFILER = None
+    assert _names(prof) == ["conv_thinn_bf16_kernel<2>"] * 2 and rm.dtype == torch.float32
+    actr = ops.gn_apply(h16, st, ops.XF_AFFINE_SILU).bfloat16().double().cpu().permute(0, 3, 1, 2)
+    refr = F.conv2d(actr, w_out.bfloat16().double().cpu(), None, 1, 1).permute(0, 2, 3, 1)
+    assert _rel(rm, refr) < 2e-5 and _rel(rm, r32) < 2e-2
+    assert _rel(rmb - rm, torch.tensor([0.5, -1.0, 2.0]).expand_as(refr)) < 1e-5
     # conv_out's dgrad with a bf16 result: the matrix-pipe kernel (3 -> 128 channels is a <= 4-channel contraction)
     prof = ops.PROFILER = ops.LaunchProfiler()
     try:

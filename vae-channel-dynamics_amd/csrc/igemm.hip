@@ -36,6 +36,8 @@ int launch_conv3_upwino(const vae_igemm_args& a, const float* U, hipStream_t st)
 int conv3_wino_nb();
 bool conv_thin_bf16_eligible(const vae_igemm_args& a);                  // conv_thin_bf16.hip (bf16: <= 4-channel contraction on the matrix pipe)
 int launch_conv_thin_bf16(const vae_igemm_args& a, hipStream_t st);
+bool conv_thinn_bf16_eligible(const vae_igemm_args& a);                 // (<= 4 output channels)
+int launch_conv_thinn_bf16(const vae_igemm_args& a, hipStream_t st);
 bool conv3_wino4_eligible(const vae_igemm_args& a);                     // conv3_wino4.hip (fp32 Winograd F(4x4,3x3))
 int launch_wino4_weights(const vae_igemm_args& a, float* U, hipStream_t st);
 int launch_conv3_wino4(const vae_igemm_args& a, const float* U, hipStream_t st);
@@ -827,6 +829,7 @@ extern "C" int vae_bf16_grad_image_ok(const vae_conv_geom* gp, int32_t Cout, int
 }
 
 static bool rows_thin_mfma(const vae_igemm_args& a) { return conv_thin_bf16_eligible(a) && !vae_opt().no_thin_mfma; }
+static bool rows_thinn_mfma(const vae_igemm_args& a) { return conv_thinn_bf16_eligible(a) && !vae_opt().no_thin_mfma; }
 static bool rows_is_phase(const vae_igemm_args& a) { return a.tapmask != 0 || a.a_step > 1 || a.c_step > 1; }
 static bool rows_wino(const vae_igemm_args& a) {
   const bool bkm = rows_bkm(a);
@@ -949,6 +952,8 @@ extern "C" int vae_igemm_kernel_name(const vae_igemm_args* ap, char* buf, int32_
     snprintf(buf, n, "conv_thin_bf16_kernel");
   else if (conv_smallk_eligible(a))
     snprintf(buf, n, "conv_smallk_kernel");
+  else if (conv_smalln_eligible(a) && rows_thinn_mfma(a))
+    snprintf(buf, n, "conv_thinn_bf16_kernel<%d>", a.xf);
   else if (conv_smalln_eligible(a))
     snprintf(buf, n, "conv_smalln_kernel<%d>", a.xf);
   else if (rows_use_wide_bf16(a, vec, bkm))
@@ -1050,6 +1055,11 @@ extern "C" int vae_igemm_rows(const vae_igemm_args* ap, void* stream) {
   if (a.A16 == nullptr && conv_smallk_eligible(a)) {
     if (int rc2 = launch_conv_smallk(a, st)) return rc2;
     VAE_LAUNCH_CHECK("conv_smallk");
+    return VAE_OK;
+  }
+  if (conv_smalln_eligible(a) && rows_thinn_mfma(a)) {  // bf16 mode, bf16 input: the same launch on the matrix pipe
+    if (int rc2 = launch_conv_thinn_bf16(a, st)) return rc2;
+    VAE_LAUNCH_CHECK("conv_thinn_bf16");
     return VAE_OK;
   }
   if (conv_smalln_eligible(a)) {
