@@ -313,10 +313,10 @@ __global__ __launch_bounds__(FNT, 3) void conv3_wino4_kernel(vae_igemm_args p, c
   // prologue: halo(0), halo(1) in LDS, V(0) from halo(0); the U fragments of step 0 in registers (XF != NONE: halo(2) too)
   if (XF == VAE_XF_NONE) {
     dma_halo(0, 0);
-    dma_halo(1, 1);
 #pragma unroll
     for (int i = 0; i < 6; ++i) load_b1(0, i);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    dma_halo(1, 1);  // lands under the first transform: waited for in front of the barrier that opens the loop
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // halo(0) has landed (6 fragment requests + 2 DMAs are younger)
   } else {
 #pragma unroll
     for (int i = 0; i < 6; ++i) load_b1(0, i);
@@ -331,6 +331,7 @@ __global__ __launch_bounds__(FNT, 3) void conv3_wino4_kernel(vae_igemm_args p, c
   if (wave < 4) write_v(sH, sV, I0{});
   else if (wave < 8) write_v(sH, sV, I1{});
   else write_v(sH, sV, I2{});
+  if (XF == VAE_XF_NONE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // halo(1) (and the first fragments) have landed
   __syncthreads();
 
   // One copy of the main loop per wave group (uniform per wave).  A wave's staging (LDS reads -> 48 operations -> LDS writes)
@@ -502,10 +503,12 @@ __global__ __launch_bounds__(FNT, 3) void conv3_wino4_kernel(vae_igemm_args p, c
           float v = y[bb] + bv;
           if (p.res) v += rres[q];
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, obase, a * rstep + bb * cstep, 0);
-          if (rnd == 0 && q == 0) gpv = v;
-          const float dv = v - gpv;
-          gs1 += dv;
-          gs2 += dv * dv;
+          if (p.gstat) {  // uniform (forward launches whose output feeds a GroupNorm)
+            if (rnd == 0 && q == 0) gpv = v;
+            const float dv = v - gpv;
+            gs1 += dv;
+            gs2 = fmaf(dv, dv, gs2);
+          }
           if (gnb) {  // uniform; same arithmetic per element as gn_bwd_partial_kernel (norm.hip)
             const float xh = (xin[q] - bmu) * brs;
             float du = v;

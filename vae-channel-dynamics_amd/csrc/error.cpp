@@ -43,7 +43,7 @@ static int* option_slot(const char* name) {
 }
 
 extern "C" const char* vae_last_error(void) { return g_err; }
-extern "C" int vae_abi_version(void) { return 11; }
+extern "C" int vae_abi_version(void) { return 12; }
 extern "C" int vae_sizeof_args(int32_t which) {
   return which == 0 ? (int)sizeof(vae_conv_geom) : which == 1 ? (int)sizeof(vae_igemm_args) : which == 2 ? (int)sizeof(vae_wgrad_args) : -1;
 }
