@@ -11,10 +11,11 @@ pytestmark = pytest.mark.gpu
 TRACKED = ["encoder.conv_in", "encoder.down_blocks.0.resnets.0.norm1", "decoder.up_blocks.1.resnets.0.norm1"]
 
 
-# 2x the worst per-tensor gradient error measured on MI355X (filled from profiles/r03_parity_measured.json)
-# measured worst per case, over the three fp32 paths (Winograd + activation image, Winograd fused, direct kernels):
-# R=32 2.5e-5, R=64 2.3e-5, R=40 3.6e-5, R=48 2.8e-5 -- every tensor inside north_star's 1e-4
-GRAD_TOL = {(32, 2): 5.0e-5, (64, 2): 4.6e-5, (40, 1): 7.2e-5, (48, 3): 5.6e-5}
+# 2x the worst per-tensor gradient error measured on MI355X (profiles/r03_parity_measured.json; round 4 with F(4x4,3x3) in the path:
+# profiles/r04_parity_measured.json), worst per case over the three fp32 paths (Winograd + activation image, Winograd fused, direct):
+# R=32 2.5e-5, R=64 2.3e-5 (3.9e-5 with F(4x4), inside the bar), R=40 3.6e-5, R=48 2.8e-5, R=128 4.6e-5 -- every tensor inside
+# north_star's 1e-4
+GRAD_TOL = {(32, 2): 5.0e-5, (64, 2): 4.6e-5, (40, 1): 7.2e-5, (48, 3): 5.6e-5, (128, 1): 9.3e-5}
 
 
 def ops_mod():
@@ -76,7 +77,9 @@ def _oracle_step(o, x, eps, klw):
 
 # (32,2) and (64,2): halo-tile kernels on the wide layers; (40,1) and (48,3): ragged sizes -- widths 40/20/10/5 and
 # 48/24/12/6 are no multiple of the 32-pixel tile, batch 1 / odd batch, attention over 25 / 36 tokens: flat kernels
-@pytest.mark.parametrize("R,B,klw", [(32, 2, 1e-6), (64, 2, 1e-2), (40, 1, 1e-4), (48, 3, 1e-3)])
+# (128,1) (round 4): maps of 128 / 64 / 32 pixels are whole 16 x 32 tiles: every plain 3x3 layer down to the 32-pixel level runs the
+# F(4x4,3x3) kernels, the 16-pixel level F(2x2,3x3)
+@pytest.mark.parametrize("R,B,klw", [(32, 2, 1e-6), (64, 2, 1e-2), (40, 1, 1e-4), (48, 3, 1e-3), (128, 1, 1e-4)])
 def test_forward_backward_matches_oracle(pair, R, B, klw):
     import vae_oracle as vo
     o, w = pair
