@@ -326,6 +326,20 @@ def test_narrow_side_kernels_with_bf16_wide_side(act16):
     hm = ops.conv_fwd(z, w_z, None, "c3")  # (4 -> 512 at 8 x 8: one 128-pixel tile, four channel blocks on the matrix-pipe kernel)
     refz = F.conv2d(z.bfloat16().double().cpu().permute(0, 3, 1, 2), w_z.bfloat16().double().cpu(), None, 1, 1).permute(0, 2, 3, 1)
     assert hm.dtype == torch.bfloat16 and _rel(hm, refz) < 6e-3
+    # its weight gradient on a 8 x 16 map (128 pixels per image: whole tiles; 512 x 4 channels: four 128-channel blocks of the
+    # matrix-pipe kernel); an 8 x 8 map (64 pixels) stays on the VALU kernel
+    z2 = _nhwc(torch.randn(3, 4, 8, 16, generator=gen))
+    dh2 = torch.randn(3, 8, 16, 512, generator=gen).cuda().bfloat16()
+    gwz, gbz = torch.empty(512, 3, 3, 4, device="cuda").permute(0, 3, 1, 2), torch.empty(512, device="cuda")
+    prof = ops.PROFILER = ops.LaunchProfiler()
+    try:
+        ops.conv_wgrad(dh2, z2, "c3", gwz, gbz)
+    finally:
+        ops.PROFILER = None
+    assert _names(prof) == ["wgrad_thin_bf16_kernel<true,0>"], _names(prof)
+    wz = torch.zeros(512, 4, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(z2.bfloat16().double().cpu().permute(0, 3, 1, 2), wz, None, 1, 1).backward(dh2.double().cpu().permute(0, 3, 1, 2))
+    assert _rel(gwz.cpu(), wz.grad) < 2e-6 and _rel(gbz, dh2.double().sum(dim=(0, 1, 2))) < 2e-6
     dh16 = torch.randn(B, 8, 8, 512, generator=gen).cuda().bfloat16()
     dz = ops.conv_dgrad(dh16, w_z, "c3", (8, 8))
     assert dz.dtype == torch.float32 and torch.equal(dz, ops.conv_dgrad(dh16.float(), w_z, "c3", (8, 8)))
