@@ -147,10 +147,14 @@ int vae_conv_gnb_chunks(const vae_igemm_args* a);
 /* number of chunks per image the launch for `a` (with a->gstat_groups set) would write into a->gstat, or 0 when the
  * kernel serving it has no statistics epilogue (the caller then runs vae_gn_stats_partial on the output)           */
 int vae_conv_gstat_chunks(const vae_igemm_args* a);
-/* Winograd F(2x2,3x3), fp32 forward / dgrad of plain 3x3 stride-1 layers (csrc/conv3_wino.hip).  vae_wino_ok: 1 when the layer
- * `a` describes (a->Wu ignored) is served; vae_wino_weight_floats: size of the transformed weights (16 * N * K floats);
- * vae_wino_weights: U = G g G^T of a->W (the dgrad geometry rotates and transposes), layout [K/8][16][N][8], into Wu.
- * The weights are transformed per launch because they are live (optimizer step, in-place nudges): 9 -> 16 floats per pair. */
+/* Winograd minimal filtering, fp32 forward / dgrad of plain 3x3 stride-1 layers: F(4x4,3x3) (csrc/conv3_wino4.hip: 36 positions)
+ * where the maps are whole 16 x 32 tiles and N whole 64-channel blocks (and option "no_wino4" is off), else F(2x2,3x3)
+ * (csrc/conv3_wino.hip: 16 positions); 9 positions for the upsampler geometries (csrc/conv3_upwino.hip).  vae_wino_ok: 1 when the
+ * layer `a` describes (a->Wu ignored) is served; vae_wino_weight_floats: size of the transformed weights for THAT kernel
+ * (36, 16 or 9 x N * K floats: always ask, never assume); vae_wino_weights: U = G g G^T of a->W (the dgrad geometry rotates and
+ * transposes), layout [K/8][positions][N][8], into Wu.  The weights are transformed per launch because they are live
+ * (optimizer step, in-place nudges).  Accuracy against a float64 convolution, worst element relative to the tensor's max:
+ * F(2x2) 1e-6, F(4x4) 1-2e-5 (tools/wino4_accuracy.py). */
 int vae_wino_ok(const vae_igemm_args* a);
 int64_t vae_wino_weight_floats(const vae_igemm_args* a);
 int vae_wino_weights(const vae_igemm_args* a, float* Wu, void* stream);
