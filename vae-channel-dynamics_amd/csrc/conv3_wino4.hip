@@ -15,16 +15,22 @@
 //   * U = G g G^T built per launch from the LIVE weights (vae_wino_weights), [K/8][36][N][8]: the B fragment of (position,
 //     channel block) is 16 contiguous bytes per lane, requested by the one wave that owns the position straight from L2 into
 //     registers (one register set, re-requested right behind the MFMAs that consumed it), never through LDS.
-//   * The chunk's 18 x 34 input halo is loaded once (GroupNorm + SiLU applied once per element) two steps ahead, as 8 CHANNEL
-//     PLANES of 641 floats in LDS (641 = 1 mod 32: the 8 tile columns x 4 channels a 32-lane group reads are 32 different banks;
-//     a pixel-major image would put every tile on the same 8 banks).  All 768 threads transform: thread = (tile, channel, row
-//     pair): rows {1,2}, {3,4} or {0,5} of B^T d (they share their sub-expressions pairwise), then those two rows times B: 48
-//     operations, 12 values written to the V image [36][2 k-halves][32 tiles][4] (a wave's A-fragment read of one position is
-//     1 KB, conflict-free for ds_read_b128).
-//   * One barrier per step.  The three waves of a SIMD are w, w+4, w+8: waves 4..7 multiply first and stage afterwards, the
-//     others stage first, so the matrix pipe has work while V is being built (separate copies of the loop per order: exact
-//     wait counts, conv3_wino.hip).
-//   * Epilogue per 32-channel block: accumulators through LDS ([36][32 tiles][33]), each thread takes A^T M A of its (tile,
+//   * The chunk's 18 x 34 input halo comes by LDS-DMA (buffer_load_dwordx4 ... lds, two wave-instructions per wave and step: no
+//     registers, no stores, nobody waits for it; retired by a counted vmcnt in front of the step's barrier) into a pixel-major image
+//     with 32 bytes of padding behind every 4 pixels: dword (pixel, channel) = 8 (pixel + pixel / 4) + channel, so the 4 tiles x 8
+//     channels a 32-lane group of the transform reads are 32 different banks and every patch read is base + immediate.  (The
+//     instantiations with GroupNorm(+SiLU) fused into the staging go through registers, two steps ahead, into the same image.)
+//   * All 768 threads transform: thread = (tile, channel, row pair): rows {1,2}, {3,4} or {0,5} of B^T d (they share their
+//     sub-expressions pairwise), then those two rows times B: 48 operations, 12 values written to the V image [36][2 k-halves]
+//     [32 tiles][4] (a wave's A-fragment read of one position is 1 KB, conflict-free for ds_read_b128).  The transform is cut into
+//     six slices INTERLEAVED with the wave's own groups of 4 MFMAs: measured alone the staging of a step was a chain of LDS round
+//     trips as long as its MFMA work (4400 against 4608 cycles; one after the other 6700), so each slice's latency has to pass
+//     behind the following group.  One barrier per step; one copy of the step loop per row pair (uniform per wave).
+//   * What a step still costs (tools/wino4_timing.py, profiles/r04_pmc_wino4.txt): 6300 cycles.  An fp32 MFMA runs at the fp32
+//     vector rate and vector instructions cost matrix-pipe time one for one: 64 x 72 MFMAs + 4 x 3 x 63 vector instructions per
+//     SIMD = 5364, barrier and first-fragment latency the rest.  Prologue + epilogue (one workgroup per CU: nothing beside them)
+//     are 43k cycles per tile: 30 % of a 128-channel layer's workgroup, 9 % of a 512-channel one.
+//   * Epilogue per 32-channel block: accumulators through LDS ([36][32 tiles][32 channels]), each thread takes A^T M A of its (tile,
 //     channel) pairs, adds bias / residual, writes the 4x4 outputs (lanes along channels: 128-byte rows) and leaves the
 //     GroupNorm moments of the outputs / -- dgrad launches -- the first pass of the GroupNorm backward, as conv3_wino.hip does.
 #include "common.h"
