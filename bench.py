@@ -156,20 +156,22 @@ def workload_label(dtype: str, R: int, B: int, ckpt: bool, nudge: int, tracking:
 class Job:
     """one configured training job on this rank: wrapper + trainer + tracker / classifier (+ nudger) + resident inputs"""
 
-    def __init__(self, dtype, B, R, dev, world, rank, *, tracking=True, act_fp32=False, checkpoint_decoder=False, nudge_interval=0):
+    def __init__(self, dtype, B, R, dev, world, rank, *, tracking=True, act_fp32=False, checkpoint_decoder=False, nudge_interval=0,
+                 one_rank_exchange=False):
         from models.sdxl_vae_wrapper import SDXLVAEWrapper
         from tracking.monitor import ActivityMonitor
         from classification.classifier import RegionClassifier
         from vaehip.trainer import HipTrainer
         from vaehip import ops
         self.ops, self.dev, self.world, self.rank, self.B, self.R, self.dtype = ops, dev, world, rank, B, R, dtype
+        self.dist_on = world > 1 or one_rank_exchange  # (--rccl-selftest: the collectives of the N > 1 path on a one-rank RCCL group)
         ops.ACT_BF16 = not act_fp32
         torch.manual_seed(42)
         self.w = SDXLVAEWrapper("synthetic:42", device=dev)
         self.trainer = HipTrainer(self.w, lr=1e-5, max_grad_norm=1.0, kl_weight=1e-6, lr_warmup_steps=100,
                                   max_train_steps=10000, scheduler_steps_per_update=world,
                                   mixed_precision="bf16" if dtype == "bf16" else "no", checkpoint_decoder=checkpoint_decoder,
-                                  time_comm=world > 1)
+                                  time_comm=self.dist_on, one_rank_exchange=one_rank_exchange)
         self.monitor = ActivityMonitor(self.w, TRACKING_CFG) if tracking else None
         self.classifier = RegionClassifier(self.w.vae, CLASSIFY_CFG) if tracking else None
         self.nudger = None
@@ -201,7 +203,7 @@ class Job:
         """-> (wall seconds of `steps` steps: barrier + synchronize on both sides, max over ranks; this rank's per-step
         milliseconds from one event per step on the launch stream)"""
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
-        if self.world > 1:
+        if self.dist_on:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -210,11 +212,11 @@ class Job:
             self.one_step()
             ev[i + 1].record()
         torch.cuda.synchronize()
-        if self.world > 1:
+        if self.dist_on:
             dist.barrier()
         dt = time.perf_counter() - t0
         tt = torch.tensor([dt], device=self.dev, dtype=torch.float64)
-        if self.world > 1:
+        if self.dist_on:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item()), [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
 
@@ -349,18 +351,18 @@ def hbm_block(dtype, B, R, ckpt, step_seconds):
             "frac": round(gbps / 8000.0, 4), "source": pmc["_src"]}
 
 
-def bf16_configs2_leg(dev, world, rank, steps=10, warmup=3, profile=True):
+def bf16_configs2_leg(dev, world, rank, steps=10, warmup=3, profile=True, one_rank_exchange=False):
     """BASELINE configs[2]'s per-GPU shape (256x256, batch 32, bf16 MFMA compute, tracking on) timed like the headline; an
     extra key of the one JSON line, the headline fields are untouched"""
     B, R = 32, RES
     torch.cuda.reset_peak_memory_stats(dev)
-    job = Job("bf16", B, R, dev, world, rank, tracking=True)
+    job = Job("bf16", B, R, dev, world, rank, tracking=True, one_rank_exchange=one_rank_exchange)
     for _ in range(warmup):
         job.one_step()
-    if world > 1:
+    if job.dist_on:
         job.trainer.exposed_comm_ms()
     dt, step_ms = job.timed_region(steps)
-    comm = job.comm_block(steps) if world > 1 else None
+    comm = job.comm_block(steps) if job.dist_on else None
     sc = job.trainer.last["scalars"].cpu().tolist()
     out = None
     summ = prof_dt = None
@@ -408,6 +410,10 @@ def main():
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl", help="nccl = RCCL over xGMI (the product path)")
     ap.add_argument("--one-device", action="store_true",
                     help="rehearsal on a one-GPU box: every rank uses cuda:0 (needs --dist-backend gloo; RCCL refuses two ranks per device)")
+    ap.add_argument("--rccl-selftest", action="store_true",
+                    help="with --gpus 1: form a ONE-rank RCCL process group and run every collective of the N > 1 path on it (bucketed "
+                         "ReduceOp.AVG all-reduces under the backward pass, barriers, the max-over-ranks reductions, the comm block): "
+                         "the lines a one-GPU box otherwise never executes.  The collectives are identities; the number is not a headline")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="launch the ranks, form the process group, all-reduce one number and print it: the multi-rank "
                          "plumbing without touching a GPU (CPU test of the launcher, with --dist-backend gloo)")
@@ -445,25 +451,30 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    selftest = bool(args.rccl_selftest) and world == 1
     if world > 1:
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
+    elif selftest:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        dist.init_process_group(args.dist_backend, rank=0, world_size=1, **({"device_id": dev} if args.dist_backend == "nccl" else {}))
 
     job = Job(args.dtype, args.batch, args.res, dev, world, rank, tracking=not args.no_tracking, act_fp32=args.act_fp32,
-              checkpoint_decoder=args.checkpoint_decoder, nudge_interval=args.nudge_interval)
+              checkpoint_decoder=args.checkpoint_decoder, nudge_interval=args.nudge_interval, one_rank_exchange=selftest)
     B, R = args.batch, args.res
     for _ in range(args.warmup):
         job.one_step()
-    if world > 1:
+    if job.dist_on:
         job.trainer.exposed_comm_ms()  # discard the warm-up's wait events (first-step RCCL initialisation included)
 
     # ---- the headline region: EXACTLY --steps steps between barrier + synchronize; one event per step (for the median), no
     # per-kernel events (those run in the profiled region below, whose cost is printed next to this one)
     dt, step_ms = job.timed_region(args.steps)
     sc = job.trainer.last["scalars"].cpu().tolist()
-    comm = job.comm_block(args.steps) if world > 1 else None
+    comm = job.comm_block(args.steps) if job.dist_on else None
 
     # ---- profiled region (rank 0 records two HIP events around every kernel launch, on the launch stream): roofline + kernels
     summ, prof_dt, prof_steps = None, None, 0
@@ -489,7 +500,7 @@ def main():
         torch.cuda.empty_cache()
         try:
             bf16_leg = bf16_configs2_leg(dev, world, rank, steps=max(3, min(args.steps, 10)), warmup=max(2, min(args.warmup, 3)),
-                                         profile=not args.no_profile)
+                                         profile=not args.no_profile, one_rank_exchange=selftest)
         except Exception as e:  # the headline must survive a failure of the extra leg
             bf16_leg = {"error": f"{type(e).__name__}: {e}"}
 
@@ -523,8 +534,10 @@ def main():
             "roofline": roof, "step_flops": step_flops, "hbm_step": hbm, "tracker_overhead": tracker,
             "bf16_configs2": bf16_leg, "cpu_baseline": cpu, "comm": comm, "kernels": kernels,
         }
+        if selftest:
+            line["rccl_selftest"] = "one-rank process group: the collectives of the N > 1 path ran as identities (see comm)"
         print(json.dumps(line))
-    if world > 1:
+    if world > 1 or selftest:
         dist.destroy_process_group()
 
 

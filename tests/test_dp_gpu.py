@@ -114,3 +114,67 @@ def test_two_rank_step_equals_mean_gradient_step(cuda, accum, backend):
         # buckets were launched from the top of the arena downwards and cover it exactly once
         assert l0 == l1 and l0[0][1] == 83_653_872 and l0[-1][0] == 0
         assert all(l0[i][0] == l0[i + 1][1] for i in range(len(l0) - 1))
+
+
+def _one_rank_worker(port, q):
+    import sys
+    for p in (os.path.join(ROOT, "vae-channel-dynamics_amd", "src"), os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        import vae_oracle as vo
+        from models.sdxl_vae_wrapper import SDXLVAEWrapper
+        from vaehip.trainer import HipTrainer
+        R, B = 32, 2
+        xs = [vo.synthetic_pixels(B, R, 42, 10 + r).to(dev) for r in range(3)]
+        es = [vo.synthetic_eps(B, R, 42, 10 + r).to(dev) for r in range(3)]
+        out = {}
+        for name, kw in (("exchange", dict(one_rank_exchange=True, time_comm=True, bucket_mb=32.0)), ("plain", {})):
+            for accum in (1, 3):
+                w = SDXLVAEWrapper("synthetic:7", device=dev)
+                tr = HipTrainer(w, lr=1e-3, lr_warmup_steps=0, max_train_steps=100, kl_weight=1e-4, max_grad_norm=1.0,
+                                gradient_accumulation_steps=accum, **kw)
+                assert tr.exchanging == (name == "exchange")
+                for j in range(3):
+                    tr.train_step(xs[j], es[j])
+                assert tr.global_step == (3 if accum == 1 else 1)
+                torch.cuda.synchronize()
+                out[(name, accum)] = w.vae.arena.flat.clone()
+                if name == "exchange":
+                    launched = list(tr.reducer.launched)
+                    assert launched[0][1] == w.vae.arena.grad.numel() and launched[-1][0] == 0
+                    assert all(launched[i][0] == launched[i + 1][1] for i in range(len(launched) - 1))
+                    assert tr.reducer._avg  # the RCCL branch: ReduceOp.AVG, no host-side division
+                    ms = tr.exposed_comm_ms()
+                    assert 0.0 <= ms < 1e4
+        same = all(torch.equal(out[("exchange", a)], out[("plain", a)]) for a in (1, 3))
+        moved = float((out[("plain", 1)] - SDXLVAEWrapper("synthetic:7", device=dev).vae.arena.flat).abs().max())
+        q.put((same, moved, dist.get_backend()))
+    except BaseException:  # the parent must see the failure instead of waiting for the queue
+        import traceback
+        q.put((False, -1.0, traceback.format_exc()))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_rank_rccl_group_runs_the_exchange(cuda):
+    """The `nccl` (= RCCL) lines on a one-GPU box: a one-rank process group, the trainer told to exchange anyway
+    (`one_rank_exchange`): communicator set-up with `device_id`, bucketed async `ReduceOp.AVG` all-reduces issued from the
+    backward watermarks against kernels launched through the raw stream pointer, the stream waits of `finish()`, the
+    accumulated-sum reducer of gradient accumulation, the parameter broadcast.  On one rank every collective is an identity, so the
+    parameters after three steps must equal, bit for bit, those of a trainer that never touches torch.distributed."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_one_rank_worker, args=(_free_port(), q))
+    p.start()
+    same, moved, backend = q.get(timeout=600)
+    p.join(timeout=120)
+    assert backend == "nccl", backend
+    assert p.exitcode == 0
+    assert same
+    assert moved > 0

@@ -31,8 +31,13 @@ class GradBucketReducer:
     """engine calls ready(low): every gradient at arena offset >= low is final.  Buckets whose
     whole range is final are all-reduced asynchronously; finish() waits and averages."""
 
-    def __init__(self, flat_grad: torch.Tensor, group=None, bucket_mb: float = 64.0, time_finish: bool = False):
+    def __init__(self, flat_grad: torch.Tensor, group=None, bucket_mb: float = 64.0, time_finish: bool = False,
+                 one_rank_exchange: bool = False):
         self.flat = flat_grad
+        # one_rank_exchange: issue the collectives on a ONE-rank group as well (they are identities there).  A self-test of the
+        # RCCL lines on a one-GPU box -- communicator, ReduceOp.AVG, async work objects against kernels launched through the raw
+        # stream pointer, the stream waits of finish() -- not something a training run sets.
+        self.one_rank_exchange = bool(one_rank_exchange)
         # exposed communication: how long the compute stream sits in finish() waiting for collectives that the
         # backward pass did not hide.  On the GPU a work.wait() only makes the stream wait (the host runs on), so the
         # figure comes from two events around the waits; read it with exposed_ms() after a synchronize.
@@ -41,6 +46,7 @@ class GradBucketReducer:
         self.last_finish_ms = 0.0
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (self.one_rank_exchange and dist.is_initialized())
         self.buckets = plan_buckets(flat_grad.numel(), int(bucket_mb * (1 << 20) / 4))
         self._next = 0
         self._works = []
@@ -54,7 +60,7 @@ class GradBucketReducer:
         self.launched = []
 
     def ready(self, low: int):
-        if self.world == 1:
+        if not self.active:
             return
         while self._next < len(self.buckets) and self.buckets[self._next][0] >= low:
             lo, hi = self.buckets[self._next]
@@ -65,7 +71,7 @@ class GradBucketReducer:
             self._next += 1
 
     def finish(self):
-        if self.world == 1:
+        if not self.active:
             return
         self.ready(0)
         ev = None
@@ -102,16 +108,16 @@ class GradBucketReducer:
         return float(self.last_finish_ms)
 
 
-def broadcast_params(flat: torch.Tensor, src: int = 0, group=None):
+def broadcast_params(flat: torch.Tensor, src: int = 0, group=None, one_rank_exchange: bool = False):
     """initial replica sync (DDP does this at wrap time) and re-sync after an intervention
     (fixes the reference's rank-0-only nudge divergence)."""
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_initialized() and (dist.get_world_size(group) > 1 or one_rank_exchange):
         dist.broadcast(flat, src=src, group=group)
 
 
-def allreduce_mean_(t: torch.Tensor, group=None) -> torch.Tensor:
+def allreduce_mean_(t: torch.Tensor, group=None, one_rank_exchange: bool = False) -> torch.Tensor:
     """coalesced logging scalars / tracker vectors (train.py:292-294 uses 3 gathers + 3 .item())."""
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_initialized() and (dist.get_world_size(group) > 1 or one_rank_exchange):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         t.mul_(1.0 / dist.get_world_size(group))
     return t

@@ -26,7 +26,8 @@ class HipTrainer:
     def __init__(self, wrapper, *, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=1.0,
                  kl_weight=1e-6, lr_warmup_steps=100, max_train_steps=1000, scheduler_steps_per_update: int = 1,
                  bucket_mb: float = 64.0, generator: Optional[torch.Generator] = None, mixed_precision: str = "no",
-                 gradient_accumulation_steps: int = 1, checkpoint_decoder: bool = False, time_comm: bool = False):
+                 gradient_accumulation_steps: int = 1, checkpoint_decoder: bool = False, time_comm: bool = False,
+                 one_rank_exchange: bool = False):
         self.wrapper = wrapper
         self.vae = wrapper.vae
         self.kl_weight = float(kl_weight)
@@ -48,10 +49,14 @@ class HipTrainer:
         # accelerate steps the scheduler num_processes times per optimizer step (accelerate/scheduler.py:72-82)
         self.scheduler_steps_per_update = int(scheduler_steps_per_update)
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        # the gradient exchange runs when there is someone to exchange with -- or, as a self-test of the RCCL path on a one-GPU
+        # box (dp.GradBucketReducer.one_rank_exchange), on a one-rank process group
+        self.one_rank_exchange = bool(one_rank_exchange) and dist.is_initialized()
+        self.exchanging = self.world > 1 or self.one_rank_exchange
         self.reducer: Optional[GradBucketReducer] = None   # made on first use (arena.grad exists after the first backward)
         self._accum_reducer: Optional[GradBucketReducer] = None
-        if self.world > 1:
-            broadcast_params(self.vae.arena.flat, 0)
+        if self.exchanging:
+            broadcast_params(self.vae.arena.flat, 0, one_rank_exchange=self.one_rank_exchange)
         self.global_step = 0
         self.last = None
 
@@ -61,7 +66,7 @@ class HipTrainer:
         return self.micro_step == 0
 
     def _make_reducer(self, flat: torch.Tensor) -> GradBucketReducer:
-        return GradBucketReducer(flat, bucket_mb=self.bucket_mb, time_finish=self.time_comm)
+        return GradBucketReducer(flat, bucket_mb=self.bucket_mb, time_finish=self.time_comm, one_rank_exchange=self.one_rank_exchange)
 
     def _accumulating_step(self, pixel_values, eps, end_of_dataloader: bool):
         """one micro-batch of an N-micro-batch update; returns (result, update_due).  The update is due on the N-th
@@ -75,7 +80,7 @@ class HipTrainer:
         grad = self.vae.arena.grad
         due = (self.micro_step + 1 == self.accum_steps) or bool(end_of_dataloader)
         first = self.micro_step == 0
-        exchange = due and self.world > 1
+        exchange = due and self.exchanging
         acc_red = None
         if exchange:
             if not first:
@@ -124,7 +129,7 @@ class HipTrainer:
                 return res
             self.micro_step = 0
         else:
-            if self.world > 1:
+            if self.exchanging:
                 if self.reducer is None or self.reducer.flat.data_ptr() != self.vae.arena.grad.data_ptr():
                     self.reducer = self._make_reducer(self.vae.arena.grad)
                 self.reducer.begin()
@@ -133,7 +138,7 @@ class HipTrainer:
                 res = eng.forward_backward(pixel_values, eps, self.kl_weight, True, self.generator)
             finally:
                 eng.reducer = None
-            if self.world > 1:
+            if self.exchanging:
                 self.reducer.finish()
         self._update()
         self.last = res
@@ -151,8 +156,8 @@ class HipTrainer:
             return
         grad = self.vae.arena.grad
         grad.copy_(self._accum)
-        if self.world > 1:
-            allreduce_mean_(grad)
+        if self.exchanging:
+            allreduce_mean_(grad, one_rank_exchange=self.one_rank_exchange)
         self.micro_step = 0
         self._update()
 
