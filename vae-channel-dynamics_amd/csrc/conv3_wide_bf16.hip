@@ -313,29 +313,21 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
     float gs1[4][2], gs2[4][2], gpv[4][2];  // statistics as shifted sums around the lane's first value
     if (p.out_bf16) {
       // bf16 output (uniform): adjacent lanes hold adjacent channels of the same 16 pixels; they swap every other register, so a
-      // lane ends up with BOTH channels of its pair at 8 pixels: 4-byte stores, 4-byte loads of the bf16 residual (res_bf16), bias
-      // of both channels.  The statistics epilogue below sums the ROUNDED values (the tensor as stored); a lane's 16 values still
-      // belong to one group, so the group merge is the same as for fp32 outputs.
-      const bool odd = lr & 1;
+      // lane ends up with BOTH channels of its pair at 8 pixels, adds the bias of both (and the bf16 residual, res_bf16: 4-byte
+      // loads) and rounds once.  The statistics epilogue below sums the ROUNDED values (the tensor as stored); a lane's 16 values
+      // still belong to one group, so the group merge is the same as for fp32 outputs.
+      // Without a residual (every dgrad, conv1 of a block) the rounded pairs then go through two more exchanges -- lanes 2 apart
+      // (quad permute, 4 channels x 4 pixels), lanes 4 apart (bank-masked row shifts, 8 channels x 2 pixels) -- and leave as TWO
+      // 16-byte stores per 32 x 32 block instead of eight 4-byte ones.  One wave per SIMD, nothing beside it: the 64 store
+      // instructions of a tile cost 3.1k of its epilogue's 9.2k cycles and kept the next tile's first loads waiting (1.3-1.9k of its
+      // main loop); a quarter as many 16-byte stores cost 1.0k (diagnostic builds, tools/wide_timing.py).  The variants are compiled
+      // per (residual, statistics, wide stores): without them the residual and statistics arithmetic ran on zeros (21 vector
+      // instructions per pair of values where a dgrad needs 11).
+      const bool odd = lr & 1, bit1 = lr & 2;
       const size_t ob16 = (size_t)(g.Ho * cs) * (g.Wo * cs) * p.ldc * 2u;
       const auto rsC16 = VAE_BUF_RSRC(reinterpret_cast<u16*>(p.C) + (int64_t)cur.b * (g.Ho * cs) * (g.Wo * cs) * p.ldc, ob16);
       const auto rsR16 = VAE_BUF_RSRC(reinterpret_cast<const u16*>(p.res ? p.res : p.C) + (int64_t)cur.b * (g.Ho * cs) * (g.Wo * cs) * p.ldc, ob16);
-      // byte offset of the lane pair's two channels at pixel e = 2 j + odd of block (r, ni): a per-lane base (the pixel of j = 0) plus
-      // a wave-uniform step -- the tiles are full (eligibility), only a channel beyond N needs masking: its base is 2 GB, beyond any
-      // tensor the 32-bit offsets address, and stays out of range when the step is added.  (The address arithmetic per store was a
-      // quarter of the epilogue's VALU work.)
-      unsigned b2[4][2];
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-          const int oy = cur.y0 + 4 * wm + r, col = cur.n0 + wn * 64 + ni * 32 + lr;
-          const int ox = cur.x0 + (odd ? 1 : 0) + 4 * lh;
-          b2[r][ni] = col < p.N ? (unsigned)((((oy * cs + (KS == 2 ? p.c_oy : 0)) * (g.Wo * cs) + ox * cs + (KS == 2 ? p.c_ox : 0)) * p.ldc + (col & ~1)) * 2)
-                                : 0x80000000u;
-        }
       const unsigned pstep = (unsigned)(cs * p.ldc * 2);  // bytes per pixel step of the row grid
-      auto off2 = [&](int r, int ni, int e) -> unsigned { return b2[r][ni] + (unsigned)(2 * ((e >> 1) & 1) + 8 * (e >> 2)) * pstep; };
       // the bias of the lane pair's channels, both channel blocks: loaded ONCE per tile, before the first store.  (Loaded per
       // 16-pixel block, each load sat behind the previous block's stores and its wait -- vmcnt counts stores too -- made every
       // block wait for the write acknowledgements of the one before: 8 store round trips per tile, 10 of a 128-channel tile's 42
@@ -347,42 +339,101 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
         pb0[ni] = (p.bias && col < p.N) ? p.bias[col & ~1] : 0.f;
         pb1[ni] = (p.bias && col < p.N) ? p.bias[col | 1] : 0.f;
       }
+      auto epi16 = [&](auto res_c, auto gst_c, auto wide_c) {
+        constexpr bool RES = decltype(res_c)::value, GST = decltype(gst_c)::value, WIDE = decltype(wide_c)::value;
+        static_assert(!(RES && WIDE), "the residual is added before the rounding, in the 4-byte layout");
+        // byte offset of a store of block (r, ni): a per-lane base plus a wave-uniform step -- the tiles are full (eligibility), only
+        // a channel beyond N needs masking: its base is 2 GB, beyond any tensor the 32-bit offsets address, and stays out of range
+        // when the step is added.  (The address arithmetic per store was a quarter of the epilogue's VALU work.)
+        //   4-byte stores: the pair's two channels at pixel  odd + 4 lh + 2 (j & 1) + 8 (j >> 1),  j = 0..7
+        //   16-byte stores: channels 8 (lr >> 3) .. + 7 at pixel  (lr & 3) + 4 lh + 8 ((lr >> 2) & 1) + 16 t,  t = 0, 1
+        unsigned b2[4][2];
 #pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        unsigned rr[4][8];
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+          for (int ni = 0; ni < 2; ++ni) {
+            const int oy = cur.y0 + 4 * wm + r, col = cur.n0 + wn * 64 + ni * 32 + lr;
+            const int ox = cur.x0 + 4 * lh + (WIDE ? (lr & 3) + 2 * (lr & 4) : (odd ? 1 : 0));
+            const int c0 = WIDE ? (col & ~7) : (col & ~1);
+            b2[r][ni] = col < p.N ? (unsigned)((((oy * cs + (KS == 2 ? p.c_oy : 0)) * (g.Wo * cs) + ox * cs + (KS == 2 ? p.c_ox : 0)) * p.ldc + c0) * 2)
+                                  : 0x80000000u;
+          }
+        auto off2 = [&](int r, int ni, int j) -> unsigned { return b2[r][ni] + (unsigned)(2 * (j & 1) + 8 * (j >> 1)) * pstep; };
 #pragma unroll
-          for (int j = 0; j < 8; ++j) rr[q][j] = 0u;
-        if (p.res) {  // uniform: the residual of half the wave's tile in flight before any of it is consumed
+        for (int hf = 0; hf < 2; ++hf) {
+          unsigned rr[4][8];
+          if constexpr (RES) {  // the residual of half the wave's tile in flight before any of it is consumed
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) rr[q][j] = __builtin_amdgcn_raw_buffer_load_b32(rsR16, off2(2 * hf + (q >> 1), q & 1, 2 * j + (odd ? 1 : 0)), 0, 0);
-        }
+              for (int j = 0; j < 8; ++j) rr[q][j] = __builtin_amdgcn_raw_buffer_load_b32(rsR16, off2(2 * hf + (q >> 1), q & 1, j), 0, 0);
+          }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int r = 2 * hf + (q >> 1), ni = q & 1;
-          const float b0 = pb0[ni], b1 = pb1[ni];
-          gs1[r][ni] = gs2[r][ni] = gpv[r][ni] = 0.f;
+          for (int q = 0; q < 4; ++q) {
+            const int r = 2 * hf + (q >> 1), ni = q & 1;
+            const float b0 = pb0[ni], b1 = pb1[ni];
+            gs1[r][ni] = gs2[r][ni] = gpv[r][ni] = 0.f;
+            unsigned P[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float a0 = acc[r][ni][2 * j], a1 = acc[r][ni][2 * j + 1];
-            const float recv = lane_xor1(odd ? a0 : a1);
-            typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-            bf16x2_t h;
-            h[0] = (__bf16)((odd ? recv : a0) + b0 + __builtin_bit_cast(float, rr[q][j] << 16));
-            h[1] = (__bf16)((odd ? a1 : recv) + b1 + __builtin_bit_cast(float, rr[q][j] & 0xffff0000u));
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, h), rsC16, off2(r, ni, 2 * j + (odd ? 1 : 0)), 0, 0);
-            const float q0 = (float)h[0], q1 = (float)h[1];
-            if (j == 0) gpv[r][ni] = q0;
-            const float d0 = q0 - gpv[r][ni], d1 = q1 - gpv[r][ni];  // (the statistics epilogue only runs on full tiles)
-            gs1[r][ni] += d0 + d1;
-            gs2[r][ni] += d0 * d0 + d1 * d1;
-            acc[r][ni][2 * j] = 0.f;
-            acc[r][ni][2 * j + 1] = 0.f;
+            for (int j = 0; j < 8; ++j) {
+              const float a0 = acc[r][ni][2 * j], a1 = acc[r][ni][2 * j + 1];
+              const float recv = lane_xor1(odd ? a0 : a1);
+              typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+              bf16x2_t h;
+              float v0 = (odd ? recv : a0) + b0, v1 = (odd ? a1 : recv) + b1;
+              if constexpr (RES) {
+                v0 += __builtin_bit_cast(float, rr[q][j] << 16);
+                v1 += __builtin_bit_cast(float, rr[q][j] & 0xffff0000u);
+              }
+              h[0] = (__bf16)v0;
+              h[1] = (__bf16)v1;
+              P[j] = __builtin_bit_cast(unsigned, h);
+              if constexpr (!WIDE) __builtin_amdgcn_raw_buffer_store_b32(P[j], rsC16, off2(r, ni, j), 0, 0);
+              if constexpr (GST) {
+                const float q0 = (float)h[0], q1 = (float)h[1];
+                if (j == 0) gpv[r][ni] = q0;
+                const float d0 = q0 - gpv[r][ni], d1 = q1 - gpv[r][ni];  // (the statistics epilogue only runs on full tiles)
+                gs1[r][ni] += d0 + d1;
+                gs2[r][ni] += d0 * d0 + d1 * d1;
+              }
+              acc[r][ni][2 * j] = 0.f;
+              acc[r][ni][2 * j + 1] = 0.f;
+            }
+            if constexpr (WIDE) {
+              // lanes 2 apart: lane (lr & 2) == 0 keeps the even j of each (j, j + 1) and gets its neighbour's: 4 channels at pixel j
+              unsigned Q[4][2];
+#pragma unroll
+              for (int jj = 0; jj < 4; ++jj) {
+                const unsigned A = P[2 * jj], Bv = P[2 * jj + 1];
+                const unsigned got = (unsigned)__builtin_amdgcn_mov_dpp((int)(bit1 ? A : Bv), 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+                Q[jj][0] = bit1 ? got : A;
+                Q[jj][1] = bit1 ? Bv : got;
+              }
+              // lanes 4 apart (the neighbouring bank of the row): bank-masked row shifts write only the lanes that receive
+#pragma unroll
+              for (int t = 0; t < 2; ++t) {
+                u32x4 o;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                  const unsigned X = Q[2 * t][k], Y = Q[2 * t + 1][k];
+                  o[k] = (unsigned)__builtin_amdgcn_update_dpp((int)X, (int)Y, 0x114, 0xF, 0xA, false);      // banks 1, 3: Y of lane - 4
+                  o[2 + k] = (unsigned)__builtin_amdgcn_update_dpp((int)Y, (int)X, 0x104, 0xF, 0x5, false);  // banks 0, 2: X of lane + 4
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(o, rsC16, b2[r][ni] + (unsigned)(16 * t) * pstep, 0, 0);
+              }
+            }
           }
         }
+      };
+      constexpr std::true_type yes{};
+      constexpr std::false_type no{};
+      const bool wide_st = (p.ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15u) == 0);
+      if (p.res) {  // uniform
+        if (p.gstat) epi16(yes, yes, no); else epi16(yes, no, no);
+      } else if (wide_st) {
+        if (p.gstat) epi16(no, yes, yes); else epi16(no, no, yes);
+      } else {
+        if (p.gstat) epi16(no, yes, no); else epi16(no, no, no);
       }
     } else {
       // fp32 output (+ bias, + residual).  The residual is HBM-cold: its loads are issued for HALF of the wave's tile (two
