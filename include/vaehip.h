@@ -39,11 +39,13 @@ int vae_sizeof_args(int32_t which);
  * everywhere: the second algorithm of the two-algorithm tests), "no_wino" (fp32: the direct halo-tile kernels instead of the
  * Winograd ones: the parity reference), "no_wino4" (fp32: F(2x2,3x3) also on the layers F(4x4,3x3) would serve; a Wu image
  * must be built and consumed under the same value: vae_wino_weight_floats / vae_wino_weights / vae_igemm_rows all follow it),
- * "no_thin_mfma" (bf16: the <= 4-channel-side layers stay on the VALU kernels), "no_wide" (bf16: the 128-pixel halo-tile kernel instead of the wide-tile one).
+ * "no_thin_mfma" (bf16: the <= 4-channel-side layers stay on the VALU kernels), "no_wide" (bf16: the 128-pixel halo-tile kernel instead of the wide-tile one),
+ * "no_wgrad_dma" (bf16: the 3x3 weight gradient stages its bf16 images through registers instead of by LDS-DMA; same result bit for bit).
  * One option is a count, not a switch: "wide_reserved_cus" (0..128, default 0): the persistent bf16 wide-tile kernel launches
  * 256 - n workgroups instead of one per CU, leaving n CUs to RCCL's workgroups while gradient buckets are in flight
  * (data-parallel runs: reference src/train.py:204-211); any grid covers all tiles, so results do not depend on it.
- * Initial values come from VAEHIP_FLAT_CONV / VAEHIP_NO_WINO / VAEHIP_NO_WIDE / VAEHIP_WIDE_RESERVED_CUS, read ONCE when the
+ * Initial values come from VAEHIP_FLAT_CONV / VAEHIP_NO_WINO / VAEHIP_NO_WINO4 / VAEHIP_NO_WIDE / VAEHIP_NO_THIN_MFMA / VAEHIP_NO_WGRAD_DMA /
+ * VAEHIP_WIDE_RESERVED_CUS, read ONCE when the
  * library is loaded.  vae_get_option returns the value, or -1 for an unknown name. */
 int vae_set_option(const char* name, int32_t value);
 int vae_get_option(const char* name);

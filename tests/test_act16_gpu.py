@@ -388,3 +388,41 @@ def test_storage_flags_are_refused_where_no_kernel_honours_them(cuda):
     assert lib.query("vae_conv_io16_ok", C.byref(a)) == 0
     with pytest.raises(VaeHipError):
         lib.call("vae_igemm_rows", C.byref(a), ops._stream())
+
+
+@pytest.mark.parametrize("kind,B,H,W,Ci,Co", [("c3", 2, 16, 32, 64, 128),      # one ci block, one co block
+                                               ("c3", 3, 8, 64, 128, 256),      # 2 x 2 blocks, units beyond the last one requested
+                                               ("c3", 1, 64, 64, 256, 136),     # a co tail: channels beyond M are never fetched
+                                               ("c3", 5, 6, 96, 192, 128),      # three ci blocks, odd unit counts per split
+                                               ("c3up", 2, 8, 32, 128, 128)])   # upsampler: the four phase launches (sub-sampled dY view, tap masks)
+def test_weight_gradient_staged_by_lds_dma_equals_register_staging(act16, kind, B, H, W, Ci, Co):
+    """wgrad3_dma_bf16_kernel (both operands as bf16 images, staged by LDS-DMA into swizzled images) against
+    wgrad3_tile_bf16_kernel (library option no_wgrad_dma: the same images through registers into padded images): same MFMA order,
+    same bias-sum order -> bitwise the same dW and db; and against torch on the rounded operands."""
+    from vaehip import ops
+    gen = torch.Generator().manual_seed(101 + B + Ci + Co)
+    x16 = _nhwc(torch.randn(B, Ci, H, W, generator=gen) * 1.1 - 0.2).bfloat16()
+    Ho, Wo = ops.out_hw(kind, H, W)
+    dy16 = torch.randn(B, Ho, Wo, Co, generator=gen).cuda().bfloat16()
+    wshape = torch.empty(Co, 3, 3, Ci, device="cuda")
+    out = {}
+    for dma in (True, False):
+        gw = torch.full_like(wshape, float("nan")).permute(0, 3, 1, 2)
+        gb = torch.full((Co,), float("nan"), device="cuda")
+        prof = ops.PROFILER = ops.LaunchProfiler()
+        try:
+            with ops.option("no_wgrad_dma", 0 if dma else 1):
+                ops.conv_wgrad(dy16, x16, kind, gw, gb)
+        finally:
+            ops.PROFILER = None
+        names = [n for n in _names(prof) if n.startswith("wgrad3_")]
+        assert names and all(n.startswith("wgrad3_dma_bf16_kernel" if dma else "wgrad3_tile_bf16_kernel") for n in names), _names(prof)
+        out[dma] = (gw.clone(), gb.clone())
+    assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][1], out[False][1])
+    xr = x16.float().cpu().permute(0, 3, 1, 2)
+    if kind == "c3up":
+        xr = F.interpolate(xr, scale_factor=2.0, mode="nearest")
+    wg = torch.zeros(Co, Ci, 3, 3, requires_grad=True)
+    F.conv2d(xr, wg, None, 1, 1).backward(dy16.float().cpu().permute(0, 3, 1, 2))
+    assert _rel(out[True][0].cpu(), wg.grad) < 3e-5
+    assert _rel(out[True][1].cpu(), dy16.float().sum((0, 1, 2)).cpu()) < 1e-5

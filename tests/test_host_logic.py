@@ -258,6 +258,9 @@ def test_fp32_activation_image_policy(monkeypatch):
     assert ops.PRECISION == ops.PREC_F32 and ops.WINOGRAD
     assert ops.get_option("no_wino") == 0 and ops.get_option("flat_conv") == 0 and ops.get_option("bogus") == -1
     # "wide_reserved_cus" is a count (CUs the persistent bf16 kernel leaves to RCCL), range-checked by the library
+    assert ops.get_option("no_wgrad_dma") == 0 and ops.get_option("no_thin_mfma") == 0 and ops.get_option("no_wino4") == 0
+    with ops.option("no_wgrad_dma"):
+        assert ops.get_option("no_wgrad_dma") == 1
     assert ops.get_option("wide_reserved_cus") == 0
     with ops.option("wide_reserved_cus", 32):
         assert ops.get_option("wide_reserved_cus") == 32

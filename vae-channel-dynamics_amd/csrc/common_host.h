@@ -13,6 +13,7 @@ struct vae_options {
   int no_wino4;   // fp32: Winograd F(2x2,3x3) also where F(4x4,3x3) would serve the layer (A/B switch, second Winograd algorithm of the tests)
   int no_thin_mfma;  // bf16: the <= 4-channel-side layers on the VALU kernels (skinny.hip) also where the matrix-pipe kernels would serve them
   int no_wide;    // bf16: the 128-pixel halo-tile kernel instead of the wide-tile one
+  int no_wgrad_dma;  // bf16: the 3x3 weight gradient stages its bf16 images through registers (A/B switch for the LDS-DMA kernel)
   // bf16, data parallel: the persistent wide-tile kernel launches (256 - n) workgroups instead of one per CU, leaving n CUs
   // to RCCL's workgroups while gradient buckets are in flight (0 = all 256; a count 0..128, not a switch)
   int wide_reserved_cus;

@@ -23,6 +23,7 @@ static vae_options init_options() {
   o.no_wide = getenv("VAEHIP_NO_WIDE") ? 1 : 0;
   o.no_wino4 = getenv("VAEHIP_NO_WINO4") ? 1 : 0;
   o.no_thin_mfma = getenv("VAEHIP_NO_THIN_MFMA") ? 1 : 0;
+  o.no_wgrad_dma = getenv("VAEHIP_NO_WGRAD_DMA") ? 1 : 0;
   const char* r = getenv("VAEHIP_WIDE_RESERVED_CUS");
   o.wide_reserved_cus = r ? atoi(r) : 0;
   if (o.wide_reserved_cus < 0 || o.wide_reserved_cus > 128) o.wide_reserved_cus = 0;
@@ -38,6 +39,7 @@ static int* option_slot(const char* name) {
   if (!strcmp(name, "no_wide")) return &g_opt.no_wide;
   if (!strcmp(name, "no_wino4")) return &g_opt.no_wino4;
   if (!strcmp(name, "no_thin_mfma")) return &g_opt.no_thin_mfma;
+  if (!strcmp(name, "no_wgrad_dma")) return &g_opt.no_wgrad_dma;
   if (!strcmp(name, "wide_reserved_cus")) return &g_opt.wide_reserved_cus;
   return nullptr;
 }
@@ -50,7 +52,7 @@ extern "C" int vae_sizeof_args(int32_t which) {
 extern "C" int vae_set_option(const char* name, int32_t value) {
   int* s = option_slot(name);
   if (!s) {
-    vae_set_error("set_option: unknown option '%s' (flat_conv, no_wino, no_wino4, no_wide, no_thin_mfma, wide_reserved_cus)", name ? name : "(null)");
+    vae_set_error("set_option: unknown option '%s' (flat_conv, no_wino, no_wino4, no_wide, no_thin_mfma, no_wgrad_dma, wide_reserved_cus)", name ? name : "(null)");
     return VAE_EINVAL;
   }
   if (s == &g_opt.wide_reserved_cus) {  // a count, not a switch

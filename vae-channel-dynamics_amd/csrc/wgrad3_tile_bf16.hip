@@ -30,6 +30,25 @@ constexpr int HQ = HPX * (BNT / 4);             // halo float4 slots (2176)
 constexpr int HI = (HQ + NT - 1) / NT;          // 3
 
 
+
+// Workgroup id -> (column = (co tile, ci tile), split).  The hardware deals consecutive workgroup ids round-robin over the 8 XCDs
+// (one L2 each).  The columns of one split stream through the SAME pixels at the same pace (every ci tile re-reads the dY rows,
+// every co tile the X halo): with id = column + columns * split the 8 columns of a 256 -> 256 layer sat on 8 different XCDs and
+// every L2 fetched the split's pixels for itself -- 1.08 GB per launch from the memory side, 3.9 TB/s, which is what the staging
+// cost (the kernel ran 0.276 ms with its DMA pieces, 0.218 with the same instructions fetching nothing).  Here XCD x takes the
+// splits congruent x mod 8, all columns of a split together: one L2 fetches a split's pixels once.
+__device__ __forceinline__ void wg_column_split(int nsplit, int& column, int& split) {
+  const int cols = gridDim.x, L = blockIdx.y * cols + blockIdx.x;
+  if (nsplit % 8 == 0) {
+    const int j = L >> 3;
+    column = j % cols;
+    split = (j / cols) * 8 + (L & 7);
+  } else {
+    column = blockIdx.x;
+    split = blockIdx.y;
+  }
+}
+
 // Y16: dY comes as a bf16 image (vae_wgrad_args.dY16): 16-byte loads written to LDS as they are
 template <bool UP, int XF, bool X16, bool Y16>
 __global__ __launch_bounds__(NT) void wgrad3_tile_bf16_kernel(vae_wgrad_args p, int tiles_x, int tiles_y, int64_t nunits) {
@@ -43,9 +62,10 @@ __global__ __launch_bounds__(NT) void wgrad3_tile_bf16_kernel(vae_wgrad_args p, 
   const int trq = (lane & 15) >> 2, trp = lane & 3, trh = (lane >> 4) & 1;
   const vae_conv_geom g = p.g;
   const int tilesN = p.N / BNT;
-  const int tm = blockIdx.x / tilesN, tn = blockIdx.x % tilesN;
+  int colw, split;
+  wg_column_split(p.nsplit, colw, split);
+  const int tm = colw / tilesN, tn = colw % tilesN;
   const int m0 = tm * BMT, n0 = tn * BNT;
-  const int split = blockIdx.y;
   const int64_t per = (nunits + p.nsplit - 1) / p.nsplit;
   const int64_t ubeg = split * per, uend = min(nunits, ubeg + per);
   const int nu = (int)max((int64_t)0, uend - ubeg);
@@ -321,6 +341,245 @@ __global__ __launch_bounds__(NT) void wgrad3_tile_bf16_kernel(vae_wgrad_args p, 
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Both operands as bf16 images (X16 and dY16: every 3x3 layer of a bf16 step): the same workgroup shape, wave roles, MFMA order
+// and epilogue as the kernel above, but the unit's two images are staged by LDS-DMA (buffer_load_dwordx4 ... lds) instead of
+// global load -> registers -> ds_write_b128.  Ablations of the register-staged kernel at 256 -> 256 channels (tools/
+// microbench_bf16.py, diagnostic builds): 0.298 ms; without the global loads 0.264; also without the LDS stores 0.219; also
+// without the barrier 0.211 -- a quarter of the kernel was staging, most of it the 16-byte LDS stores (13 cycles each through
+// the VGPR -> LDS path that all twelve waves share).  The DMA needs no registers, no stores and no waits inside the step.
+//   * A DMA wave-instruction writes 64 x 16 B lane-linear at M0: no row padding is possible inside a piece, so the images are
+//     swizzled by WHICH 16 bytes a lane fetches.  The transposing read (ds_read_b64_tr_b16) of a 32-lane group takes 4 pixel rows
+//     x 64 B; the four rows have to sit in four different 64-byte bank ranges of the 256-byte bank cycle:
+//       dY image  (256 B per pixel = four 64-byte segments): piece = 4 pixels; segment g of pixel q at  1024 (px >> 2) + 256 q +
+//                 64 ((g + q) & 3),  q = px & 3   -- the rows of a read are rotated against each other;
+//       halo image (128 B per pixel = two segments):          piece = 8 pixels; segment s of halo pixel hp at  512 (hp >> 2) + 256 s
+//                 + 64 (hp & 3)  -- four consecutive pixels are four bank ranges wherever the group starts (the tap shifts 0, 1, 2
+//                 move the group off the piece grid); a lane keeps the addresses of its pixel + 0..3, the rest is an immediate.
+//   * 33 pieces per unit (16 + 17) + 3 all-out-of-range ones: three per wave, so every wave waits for the same count.  Three
+//     stages in LDS (108 KB): the pieces of unit s + 2 are requested at the top of step s (its buffer was last read in step s - 1,
+//     behind that step's barrier), `s_waitcnt vmcnt(3)` in front of the barrier of step s retires those of unit s + 1.  Inline asm,
+//     as in conv3_wino4.hip: with a DMA it can see in flight hipcc waits for vmcnt(0) at every other load.
+//   * bias gradient (workgroups of the first ci block): the column sums of dY are read back from the LDS image, same thread ->
+//     (8 columns, pixels) assignment and same order of additions as the register-staged kernel: bitwise the same sums.
+constexpr int DPIECES = 36, DSTAGE = DPIECES * 1024;   // bytes per stage: dY image 16 KB, halo image 17 KB, 3 KB never read
+constexpr int DMA_LDS = 3 * DSTAGE;
+
+template <bool UP>
+__global__ __launch_bounds__(NT) void wgrad3_dma_bf16_kernel(vae_wgrad_args p, int tiles_x, int tiles_y, int64_t nunits) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char dsm[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int mt = wave & 1, nt = (wave >> 1) & 1, tg = wave >> 2;  // 64-row co block, 32-column ci block, filter row kh
+  const int trq = (lane & 15) >> 2, trp = lane & 3, trh = (lane >> 4) & 1;
+  const vae_conv_geom g = p.g;
+  const int tilesN = p.N / BNT;
+  int colw, split;
+  wg_column_split(p.nsplit, colw, split);
+  const int tm = colw / tilesN, tn = colw % tilesN;
+  const int m0 = tm * BMT, n0 = tn * BNT;
+  const int64_t per = (nunits + p.nsplit - 1) / p.nsplit;
+  const int64_t ubeg = split * per, uend = min(nunits, ubeg + per);
+  const int nu = (int)max((int64_t)0, uend - ubeg);
+  const int Hb = UP ? 2 * g.Hs : g.Hs, Wb = UP ? 2 * g.Ws : g.Ws;
+  const bool do_bias = (p.bias_partial != nullptr) && tn == 0;
+  const int units_per_img = tiles_x * tiles_y;
+  const int ys = (!UP && p.y_step > 1) ? p.y_step : 1;
+  const int wmask = ((p.tapmask ? p.tapmask : 0x1ff) >> (3 * tg)) & 7;
+
+  f32x16 acc[3][2];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][mi][r] = 0.f;
+
+  // ---- this lane's share of the wave's three pieces: what it fetches (per-unit part added in request()) ----
+  // piece id = 3 wave + j: 0..15 dY (pixels 4 id ..), 16..32 halo (halo pixels 8 (id - 16) ..), 33..35 nothing
+  int kind[3];        // 0 = dY, 1 = halo, 2 = none (uniform per wave)
+  unsigned yoff[3];   // dY: byte offset inside the unit's first pixel row / BUF_OOB (channel beyond M)
+  int hir[3], hjc[3], hc[3];  // halo: row and column inside the 4 x 34 halo, first channel
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int id = wave * 3 + j;
+    const int sl = lane >> 2, ci = lane & 3;
+    kind[j] = id < 16 ? 0 : (id < 33 ? 1 : 2);
+    {  // dY: slot sl of the piece = pixel q = sl >> 2, bank range sl & 3 -> segment ((sl & 3) - q) & 3
+      const int q = sl >> 2, sg = ((sl & 3) - q) & 3;
+      const int px = 4 * (id & 15) + q, c = m0 + sg * 32 + ci * 8;
+      yoff[j] = c < p.M ? (unsigned)((((px >> 5) * ys * (g.Wo * ys) + (px & 31) * ys) * p.ldy + c) * 2) : BUF_OOB;
+    }
+    {  // halo: slot sl = (quad, segment, pixel in quad)
+      const int hp = 8 * (id - 16) + 4 * (sl >> 3) + (sl & 3), sgm = (sl >> 2) & 1;
+      hir[j] = hp / HWD;
+      hjc[j] = hp - hir[j] * HWD;
+      hc[j] = n0 + sgm * 32 + ci * 8;
+    }
+  }
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)dsm);
+  // the unit to request next (image, tile row, tile column), advanced without divisions
+  int nb_ = 0, nty_ = 0, ntx_ = 0, nleft_ = nu;
+  if (nu > 0) {
+    nb_ = (int)(ubeg / units_per_img);
+    const int rem = (int)(ubeg - (int64_t)nb_ * units_per_img);
+    nty_ = rem / tiles_x;
+    ntx_ = rem - nty_ * tiles_x;
+  }
+  auto request = [&](int buf) {  // the three pieces of the next unit into stage `buf`; beyond the range: descriptors of size 0 (zeros)
+    const bool valid = nleft_ > 0;
+    const int b = nb_, y0 = nty_ * TH, x0 = ntx_ * TW;
+    --nleft_;
+    if (++ntx_ == tiles_x) {
+      ntx_ = 0;
+      if (++nty_ == tiles_y) { nty_ = 0; ++nb_; }
+    }
+    const size_t ybytes = (size_t)(g.Ho * ys) * (g.Wo * ys) * p.ldy * 2u, xbytes = (size_t)g.Hs * g.Ws * g.Cs * 2u;
+    const auto rsY = VAE_BUF_RSRC(reinterpret_cast<const u16*>(p.dY16) + (int64_t)b * (g.Ho * ys) * (g.Wo * ys) * p.ldy, valid ? ybytes : (size_t)0);
+    const auto rsX = VAE_BUF_RSRC(reinterpret_cast<const u16*>(p.X16) + (int64_t)b * g.Hs * g.Ws * g.Cs, valid ? xbytes : (size_t)0);
+    const unsigned ybase = (unsigned)((((y0 * ys + p.y_oy) * (g.Wo * ys) + x0 * ys + p.y_ox) * p.ldy) * 2);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)buf * (unsigned)DSTAGE + (unsigned)(wave * 3 + j) * 1024u);
+      unsigned keep;
+      if (kind[j] == 0) {  // uniform
+        const unsigned off = yoff[j] == BUF_OOB ? BUF_OOB : yoff[j] + ybase;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(dst), "v"(off), "s"(rsY) : "memory");
+      } else {
+        const int hy = y0 - 1 + hir[j], hx = x0 - 1 + hjc[j];
+        const bool ok = kind[j] == 1 && ((unsigned)hy < (unsigned)Hb) && ((unsigned)hx < (unsigned)Wb) && hc[j] < p.N;
+        const int sy = UP ? (hy >> 1) : hy, sx = UP ? (hx >> 1) : hx;
+        const unsigned off = ok ? (unsigned)(((sy * g.Ws + sx) * g.Cs + hc[j]) * 2) : BUF_OOB;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(dst), "v"(off), "s"(rsX) : "memory");
+      }
+    }
+  };
+
+  // ---- fragments: byte addresses inside a stage ----
+  // dY: pixel P = 16 kg + 8 lh + trq (+ 4), columns mt*64 + mi*32 + trh*16 + trp*4: P & 3 = trq
+  int aoffb[2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) aoffb[mi] = lh * 2048 + trq * 256 + (((mt * 2 + mi) + trq) & 3) * 64 + trh * 32 + trp * 8;
+  // halo: pixel hp = L + C,  L = tg*34 + 8 lh + trq,  C = r*34 + c0 + t (+ 4): address of L + m for m = 0..3, + 512 (C >> 2)
+  int boffb[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int hp = tg * HWD + lh * 8 + trq + m;
+    boffb[m] = 16 * 1024 + (hp >> 2) * 512 + nt * 256 + (hp & 3) * 64 + trh * 32 + trp * 8;
+  }
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  auto tr8 = [&](const unsigned char* lo, const unsigned char* hi) {
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lo));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(hi));
+    s16x8 r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf16x8, r);
+  };
+  auto fetch_a = [&](const unsigned char* st, int kg, bf16x8* a) {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) a[mi] = tr8(st + aoffb[mi] + kg * 4096, st + aoffb[mi] + kg * 4096 + 1024);
+  };
+  auto fetch_b = [&](const unsigned char* st, int grp) {
+    const int kg = grp / 3, t = grp - kg * 3;
+    const int C = (kg >> 1) * HWD + (kg & 1) * 16 + t;
+    return tr8(st + boffb[C & 3] + (C >> 2) * 512, st + boffb[C & 3] + ((C >> 2) + 1) * 512);
+  };
+  bf16x8 fa[2][2], fb[2];
+  auto compute = [&](const unsigned char* st) {  // the unit's 12 MFMA groups; the fragments of group i + 1 are requested before group i
+    fetch_a(st, 0, fa[0]);
+    fb[0] = fetch_b(st, 0);
+#pragma unroll
+    for (int grp = 0; grp < 12; ++grp) {
+      const int kg = grp / 3, t = grp - kg * 3;
+      if (grp + 1 < 12) {
+        if (t == 2) fetch_a(st, kg + 1, fa[(kg + 1) & 1]);
+        fb[(grp + 1) & 1] = fetch_b(st, grp + 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if ((wmask >> t) & 1) {  // uniform per wave (always true without a tap mask)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+          acc[t][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kg & 1][mi], fb[grp & 1], acc[t][mi], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // bias gradient: thread -> columns (tid & 15) * 8 .. + 7 at pixels (tid >> 4) and (tid >> 4) + 48 of the unit
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f}, bsum2 = {0.f, 0.f, 0.f, 0.f};
+  int bofs[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int q = tid + NT * i, px = q >> 4, cg = q & 15;  // 8-column group cg = segment cg >> 2, 16-byte chunk cg & 3
+    bofs[i] = q < UPX * 16 ? (px >> 2) * 1024 + (px & 3) * 256 + ((((cg >> 2) + px) & 3) * 64) + (cg & 3) * 16 : -1;
+  }
+  auto bias_sums = [&](const unsigned char* st) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (bofs[i] >= 0) {
+        const uint4 r = *reinterpret_cast<const uint4*>(st + bofs[i]);
+        bsum[0] += __builtin_bit_cast(float, r.x << 16); bsum[1] += __builtin_bit_cast(float, r.x & 0xffff0000u);
+        bsum[2] += __builtin_bit_cast(float, r.y << 16); bsum[3] += __builtin_bit_cast(float, r.y & 0xffff0000u);
+        bsum2[0] += __builtin_bit_cast(float, r.z << 16); bsum2[1] += __builtin_bit_cast(float, r.z & 0xffff0000u);
+        bsum2[2] += __builtin_bit_cast(float, r.w << 16); bsum2[3] += __builtin_bit_cast(float, r.w & 0xffff0000u);
+      }
+    }
+  };
+
+  if (nu > 0) {
+    request(0);
+    request(1);
+    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  // unit 0 has landed
+    __syncthreads();
+    int cur = 0, nxt2 = 2;
+    for (int s = 0; s < nu; ++s) {
+      request(nxt2);  // unit s + 2 (beyond the range: zeros into a buffer nobody reads)
+      const unsigned char* st = dsm + cur * DSTAGE;
+      compute(st);
+      if (do_bias) bias_sums(st);  // uniform
+      asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  // this wave's pieces of unit s + 1 have landed
+      __syncthreads();
+      cur = cur == 2 ? 0 : cur + 1;
+      nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the last two requests write LDS the bias reduction below reuses)
+    __syncthreads();
+  }
+
+  const int64_t ld = (int64_t)9 * p.N;
+  float* __restrict__ O = (p.nsplit == 1 ? p.out : p.partial + (int64_t)split * p.M * ld);
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int tap = tg * 3 + t;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int col = n0 + nt * 32 + lr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + mt * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < p.M) O[(int64_t)row * ld + (int64_t)tap * p.N + col] = p.alpha * acc[t][mi][r];
+      }
+    }
+  }
+  if (do_bias) {
+    f32x4* red = reinterpret_cast<f32x4*>(dsm);  // [NT/16][16][2]: thread t holds columns (t & 15) * 8 .. + 7
+    red[tid * 2] = bsum;
+    red[tid * 2 + 1] = bsum2;
+    __syncthreads();
+    if (tid < BMT / 4) {  // quad `tid` of the 128 columns = half (tid & 1) of column group tid >> 1
+      f32x4 t4 = {0.f, 0.f, 0.f, 0.f};
+      for (int r = 0; r < NT / 16; ++r) t4 += red[(r * 16 + (tid >> 1)) * 2 + (tid & 1)];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = m0 + tid * 4 + e;
+        if (m < p.M) p.bias_partial[(int64_t)split * p.M + m] = t4[e];
+      }
+    }
+  }
+}
+
 }  // namespace
 
 bool wgrad3_tile_bf16_eligible(const vae_wgrad_args& a, bool vec) {
@@ -335,6 +594,13 @@ bool wgrad3_tile_bf16_eligible(const vae_wgrad_args& a, bool vec) {
   if ((size_t)g.Ho * g.Wo * a.ldy * 4u * ys * ys >= BUF_MAX || (size_t)g.Hs * g.Ws * g.Cs * 4u >= BUF_MAX) return false;  // one image per descriptor
   return true;
 }
+// the LDS-DMA kernel: both operands as 16-byte-aligned bf16 images whose rows are whole 16-byte pieces
+bool wgrad3_tile_bf16_dma(const vae_wgrad_args& a) {
+  const vae_conv_geom& g = a.g;
+  if (a.X16 == nullptr || a.dY16 == nullptr || a.xf != VAE_XF_NONE || vae_opt().no_wgrad_dma) return false;
+  if (a.M % 8 != 0 || a.ldy % 8 != 0 || g.Cs % 8 != 0 || !aligned16(a.X16) || !aligned16(a.dY16)) return false;
+  return true;
+}
 int64_t wgrad3_tile_bf16_units(const vae_conv_geom& g) { return (int64_t)g.B * (g.Ho / TH) * (g.Wo / TW); }
 int wgrad3_tile_bf16_columns(const vae_wgrad_args& a) { return ((a.M + BMT - 1) / BMT) * (a.N / BNT); }
 
@@ -347,6 +613,19 @@ int launch_wgrad3_tile_bf16(const vae_wgrad_args& a, hipStream_t st) {
   const bool y16 = a.dY16 != nullptr;
 #define WG3(UPV, XFV, X16V) do { if (y16) hipLaunchKernelGGL((wgrad3_tile_bf16_kernel<UPV, XFV, X16V, true>), grid, dim3(NT), 0, st, a, tx, ty, nunits); \
                                 else hipLaunchKernelGGL((wgrad3_tile_bf16_kernel<UPV, XFV, X16V, false>), grid, dim3(NT), 0, st, a, tx, ty, nunits); } while (0)
+  if (wgrad3_tile_bf16_dma(a)) {  // both operands as bf16 images: staged by LDS-DMA
+    static bool attr_set[2] = {false, false};
+    auto kern = up ? wgrad3_dma_bf16_kernel<true> : wgrad3_dma_bf16_kernel<false>;
+    if (!attr_set[up]) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS) != hipSuccess) {
+        vae_set_error("wgrad3_dma_bf16: cannot reserve %d bytes of LDS", DMA_LDS);
+        return VAE_ELAUNCH;
+      }
+      attr_set[up] = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(NT), DMA_LDS, st, a, tx, ty, nunits);
+    return 0;
+  }
   if (a.X16 != nullptr) {  // transformed bf16 activation image (xf == NONE checked by the caller)
     if (up) WG3(true, VAE_XF_NONE, true); else WG3(false, VAE_XF_NONE, true);
     return 0;

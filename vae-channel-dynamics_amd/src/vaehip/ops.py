@@ -59,7 +59,7 @@ class precision:
 
 class option:
     """context manager over the library's process-wide kernel-selection switches (vae_set_option: "flat_conv", "no_wino",
-    "no_wino4", "no_wide", and the count "wide_reserved_cus"); the environment (VAEHIP_FLAT_CONV / VAEHIP_NO_WINO / ...) only
+    "no_wino4", "no_wide", "no_thin_mfma", "no_wgrad_dma", and the count "wide_reserved_cus"); the environment (VAEHIP_FLAT_CONV / VAEHIP_NO_WINO / ...) only
     gives their initial values"""
 
     def __init__(self, name: str, value: int = 1):
