@@ -394,12 +394,16 @@ def test_storage_flags_are_refused_where_no_kernel_honours_them(cuda):
                                                ("c3", 3, 8, 64, 128, 256),      # 2 x 2 blocks, units beyond the last one requested
                                                ("c3", 1, 64, 64, 256, 136),     # a co tail: channels beyond M are never fetched
                                                ("c3", 5, 6, 96, 192, 128),      # three ci blocks, odd unit counts per split
-                                               ("c3up", 2, 8, 32, 128, 128)])   # upsampler: the four phase launches (sub-sampled dY view, tap masks)
-def test_weight_gradient_staged_by_lds_dma_equals_register_staging(act16, kind, B, H, W, Ci, Co):
+                                               ("c3up", 2, 8, 32, 128, 128),    # upsampler: the four phase launches (sub-sampled dY view, tap masks)
+                                               ("c3up_virtual", 2, 8, 32, 128, 128)])  # upsampler as ONE launch over the virtual nearest-2x upsample
+def test_weight_gradient_staged_by_lds_dma_equals_register_staging(act16, kind, B, H, W, Ci, Co, monkeypatch):
     """wgrad3_dma_bf16_kernel (both operands as bf16 images, staged by LDS-DMA into swizzled images) against
     wgrad3_tile_bf16_kernel (library option no_wgrad_dma: the same images through registers into padded images): same MFMA order,
     same bias-sum order -> bitwise the same dW and db; and against torch on the rounded operands."""
     from vaehip import ops
+    if kind == "c3up_virtual":
+        monkeypatch.setattr(ops, "PHASE_UPCONV", False)
+        kind = "c3up"
     gen = torch.Generator().manual_seed(101 + B + Ci + Co)
     x16 = _nhwc(torch.randn(B, Ci, H, W, generator=gen) * 1.1 - 0.2).bfloat16()
     Ho, Wo = ops.out_hw(kind, H, W)
