@@ -395,7 +395,10 @@ def test_storage_flags_are_refused_where_no_kernel_honours_them(cuda):
                                                ("c3", 1, 64, 64, 256, 136),     # a co tail: channels beyond M are never fetched
                                                ("c3", 5, 6, 96, 192, 128),      # three ci blocks, odd unit counts per split
                                                ("c3up", 2, 8, 32, 128, 128),    # upsampler: the four phase launches (sub-sampled dY view, tap masks)
-                                               ("c3up_virtual", 2, 8, 32, 128, 128)])  # upsampler as ONE launch over the virtual nearest-2x upsample
+                                               ("c3up_virtual", 2, 8, 32, 128, 128),  # upsampler as ONE launch over the virtual nearest-2x upsample
+                                               ("c3s2", 3, 16, 64, 128, 128),   # stride-2 downsampler: 1 x 32-pixel units, 3 x 65 halo
+                                               ("c3s2", 2, 64, 128, 256, 264),  # several strips per row, a co tail
+                                               ("c3s2", 5, 6, 64, 64, 128)])    # odd row counts per split
 def test_weight_gradient_staged_by_lds_dma_equals_register_staging(act16, kind, B, H, W, Ci, Co, monkeypatch):
     """wgrad3_dma_bf16_kernel (both operands as bf16 images, staged by LDS-DMA into swizzled images) against
     wgrad3_tile_bf16_kernel (library option no_wgrad_dma: the same images through registers into padded images): same MFMA order,
@@ -419,14 +422,18 @@ def test_weight_gradient_staged_by_lds_dma_equals_register_staging(act16, kind, 
                 ops.conv_wgrad(dy16, x16, kind, gw, gb)
         finally:
             ops.PROFILER = None
-        names = [n for n in _names(prof) if n.startswith("wgrad3_")]
-        assert names and all(n.startswith("wgrad3_dma_bf16_kernel" if dma else "wgrad3_tile_bf16_kernel") for n in names), _names(prof)
+        other = "wgrad_bf16_kernel" if kind == "c3s2" else "wgrad3_tile_bf16_kernel"  # (stride 2 without the DMA kernel: the flat kernel)
+        names = [n for n in _names(prof) if n.startswith("wgrad")]
+        assert names and all(n.startswith("wgrad3_dma_bf16_kernel" if dma else other) for n in names), _names(prof)
         out[dma] = (gw.clone(), gb.clone())
-    assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][1], out[False][1])
+    if kind == "c3s2":  # another kernel, another order of the fp32 sums
+        assert _rel(out[True][0], out[False][0]) < 2e-5 and _rel(out[True][1], out[False][1]) < 2e-6
+    else:
+        assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][1], out[False][1])
     xr = x16.float().cpu().permute(0, 3, 1, 2)
     if kind == "c3up":
         xr = F.interpolate(xr, scale_factor=2.0, mode="nearest")
     wg = torch.zeros(Co, Ci, 3, 3, requires_grad=True)
-    F.conv2d(xr, wg, None, 1, 1).backward(dy16.float().cpu().permute(0, 3, 1, 2))
+    (F.conv2d(F.pad(xr, (0, 1, 0, 1)), wg, None, 2, 0) if kind == "c3s2" else F.conv2d(xr, wg, None, 1, 1)).backward(dy16.float().cpu().permute(0, 3, 1, 2))
     assert _rel(out[True][0].cpu(), wg.grad) < 3e-5
     assert _rel(out[True][1].cpu(), dy16.float().sum((0, 1, 2)).cpu()) < 1e-5

@@ -330,14 +330,7 @@ int launch_role(const AttnArgs& a, int B, hipStream_t st) {
   constexpr int LDS = 2 * TILE + (TILE >= EXCH ? 0 : EXCH) + 256;
   static_assert(LDS <= 160 * 1024, "LDS budget");
   auto kern = attn_kernel<BF, ROLE>;
-  static bool attr_set = false;  // > 64 KB of dynamic LDS must be allowed once per kernel
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
-      vae_set_error("vae_attn: cannot reserve %d bytes of LDS", LDS);
-      return VAE_ELAUNCH;
-    }
-    attr_set = true;
-  }
+  VAE_RESERVE_LDS(kern, LDS, "vae_attn");
   dim3 grid((unsigned)(a.T / BR), (unsigned)B);
   hipLaunchKernelGGL(kern, grid, dim3(ANT), LDS, st, a);
   return 0;

@@ -19,3 +19,19 @@ struct vae_options {
   int wide_reserved_cus;
 };
 const vae_options& vae_opt();
+
+// Kernels with more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize set once per kernel AND device
+// (one bit per device ordinal; a local static per call site, i.e. per template instantiation).  Returns VAE_ELAUNCH from the caller.
+#define VAE_RESERVE_LDS(kern, bytes, what)                                                                                  \
+  do {                                                                                                                      \
+    static unsigned long long done_ = 0;                                                                                    \
+    int dev_ = 0;                                                                                                           \
+    (void)hipGetDevice(&dev_);                                                                                              \
+    if (!((done_ >> (dev_ & 63)) & 1ull)) {                                                                                 \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)) != hipSuccess) { \
+        vae_set_error("%s: cannot reserve %d bytes of LDS", what, (int)(bytes));                                            \
+        return VAE_ELAUNCH;                                                                                                 \
+      }                                                                                                                     \
+      done_ |= 1ull << (dev_ & 63);                                                                                         \
+    }                                                                                                                       \
+  } while (0)

@@ -150,16 +150,9 @@ bool conv1_bf16_eligible(const vae_igemm_args& a) {
 
 template <bool DG, int KG>
 static int launch_conv1_t(const vae_igemm_args& a, hipStream_t st) {
-  static bool attr_set = false;
   auto kern = conv1_bf16_kernel<DG, KG>;
   const size_t lds = conv1_lds_bytes(DG, KG * 16);
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      vae_set_error("conv1_bf16: cannot reserve %d bytes of LDS", (int)lds);
-      return VAE_ELAUNCH;
-    }
-    attr_set = true;
-  }
+  VAE_RESERVE_LDS(kern, lds, "conv1_bf16");
   const int slices = a.N / C1_BN, nblocks = a.M / 32;
   const int per_cu = (KG <= 16 && 2 * lds <= 150 * 1024) ? 2 : 1;  // (K <= 256: < 256 registers per wave, two workgroups fit a CU where the weight slices do)
   const int wpn = std::max(1, std::min((256 * per_cu) / slices, (nblocks + 3) / 4));

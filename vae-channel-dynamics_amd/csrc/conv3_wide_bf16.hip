@@ -577,15 +577,8 @@ int conv3_wide_bf16_gstat_chunks(const vae_igemm_args& a) {
 
 template <bool DG, int KS>
 static int launch_wide(const vae_igemm_args& a, int tx, int ty, int64_t nt, int kh0, int kw0, hipStream_t st) {
-  static bool attr_set = false;
   auto kern = conv3_wide_bf16_kernel<DG, KS>;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
-      vae_set_error("conv3_wide_bf16: cannot reserve %d bytes of LDS", LDS_BYTES);
-      return VAE_ELAUNCH;
-    }
-    attr_set = true;
-  }
+  VAE_RESERVE_LDS(kern, LDS_BYTES, "conv3_wide_bf16");
   // persistent: one 4-wave workgroup per CU; library option "wide_reserved_cus" leaves that many CUs free (RCCL's workgroups
   // under a data-parallel backward pass): tiles are dealt t = blockIdx.x, += gridDim.x, so any grid size covers them all
   dim3 grid((unsigned)std::min<int64_t>(nt, 256 - vae_opt().wide_reserved_cus));

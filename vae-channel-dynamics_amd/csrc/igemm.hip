@@ -979,13 +979,13 @@ extern "C" int vae_wgrad_kernel_name(const vae_wgrad_args* ap, char* buf, int32_
   const vae_wgrad_args a = wgrad_canon(*ap);
   const bool vec = wgrad_vec(a);
   const char* tf[2] = {"false", "true"};
-  if (wgrad_is_phase(a) && a.prec == VAE_PREC_BF16 && wgrad3_tile_bf16_dma(a)) snprintf(buf, n, "wgrad3_dma_bf16_kernel<false>");
+  if (wgrad_is_phase(a) && a.prec == VAE_PREC_BF16 && wgrad3_tile_bf16_dma(a)) snprintf(buf, n, "wgrad3_dma_bf16_kernel<false,1>");
   else if (wgrad_is_phase(a) && a.prec == VAE_PREC_BF16)
     snprintf(buf, n, "wgrad3_tile_bf16_kernel<false,%d,%s,%s>", a.xf, tf[a.X16 != nullptr], tf[a.dY16 != nullptr]);
   else if (wgrad_is_phase(a)) snprintf(buf, n, "wgrad3_tile_kernel<%s,%d>", tf[a.g.mode == VAE_MODE_UP2X], a.xf);
   else if (wgrad_smallk_kind(a) && wgrad_smallk_on_mfma(a)) snprintf(buf, n, "wgrad_thin_bf16_kernel<%s,%d>", tf[wgrad_smallk_kind(a) == 1], a.xf);
   else if (wgrad_smallk_kind(a)) snprintf(buf, n, "wgrad_smallk_kernel<%s,%d>", tf[wgrad_smallk_kind(a) == 1], a.xf);
-  else if (wgrad_use_tile_bf16(a) && wgrad3_tile_bf16_dma(a)) snprintf(buf, n, "wgrad3_dma_bf16_kernel<%s>", tf[a.g.mode == VAE_MODE_UP2X]);
+  else if (wgrad_use_tile_bf16(a) && wgrad3_tile_bf16_dma(a)) snprintf(buf, n, "wgrad3_dma_bf16_kernel<%s,%d>", tf[a.g.mode == VAE_MODE_UP2X], a.g.stride);
   else if (wgrad_use_tile_bf16(a)) snprintf(buf, n, "wgrad3_tile_bf16_kernel<%s,%d,%s,%s>", tf[a.g.mode == VAE_MODE_UP2X], a.xf, tf[a.X16 != nullptr], tf[a.dY16 != nullptr]);
   else if (wgrad_use_tile(a)) snprintf(buf, n, "wgrad3_tile_kernel<%s,%d>", tf[a.g.mode == VAE_MODE_UP2X], a.xf);
   else if (a.prec == VAE_PREC_BF16 && vec)

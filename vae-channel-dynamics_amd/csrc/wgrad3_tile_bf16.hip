@@ -366,8 +366,17 @@ __global__ __launch_bounds__(NT) void wgrad3_tile_bf16_kernel(vae_wgrad_args p, 
 constexpr int DPIECES = 36, DSTAGE = DPIECES * 1024;   // bytes per stage: dY image 16 KB, halo image 17 KB, 3 KB never read
 constexpr int DMA_LDS = 3 * DSTAGE;
 
-template <bool UP>
+// STR = 2: the stride-2 downsampler convolutions (pad (0,1,0,1)): unit = 1 x 32 output pixels, halo = 3 rows x 65 columns -- again
+// 8 + 25 = 33 pieces.  A lane's four rows of a transposing read are then TWO halo pixels apart, so the bank range of a halo pixel is
+// (hp >> 1) & 3 instead of hp & 3:  segment s of pixel hp at  1024 (hp >> 3) + 64 (4 (2 (hp & 1) + s) + ((hp >> 1) & 3)).
+template <bool UP, int STR>
 __global__ __launch_bounds__(NT) void wgrad3_dma_bf16_kernel(vae_wgrad_args p, int tiles_x, int tiles_y, int64_t nunits) {
+  static_assert(STR == 1 || (STR == 2 && !UP), "stride 1 (plain or over a virtual upsample) or stride 2");
+  constexpr int UTH = STR == 2 ? 1 : TH, UPXS = UTH * TW;          // output rows / pixels of a unit
+  constexpr int HR = STR == 2 ? 3 : TH + 2, HWS = STR == 2 ? 2 * TW + 1 : HWD, HPXS = HR * HWS;  // halo rows, columns, pixels
+  constexpr int ND = UPXS / 4, NH = (HPXS + 7) / 8;                // dY pieces, halo pieces
+  static_assert(ND + NH <= DPIECES, "three pieces per wave");
+  constexpr int NKG = UPXS / 16;                                    // 16-pixel k-groups of a unit
   extern __shared__ __attribute__((aligned(1024))) unsigned char dsm[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -406,17 +415,18 @@ __global__ __launch_bounds__(NT) void wgrad3_dma_bf16_kernel(vae_wgrad_args p, i
   for (int j = 0; j < 3; ++j) {
     const int id = wave * 3 + j;
     const int sl = lane >> 2, ci = lane & 3;
-    kind[j] = id < 16 ? 0 : (id < 33 ? 1 : 2);
+    kind[j] = id < ND ? 0 : (id < ND + NH ? 1 : 2);
     {  // dY: slot sl of the piece = pixel q = sl >> 2, bank range sl & 3 -> segment ((sl & 3) - q) & 3
       const int q = sl >> 2, sg = ((sl & 3) - q) & 3;
-      const int px = 4 * (id & 15) + q, c = m0 + sg * 32 + ci * 8;
+      const int px = 4 * (id % ND) + q, c = m0 + sg * 32 + ci * 8;
       yoff[j] = c < p.M ? (unsigned)((((px >> 5) * ys * (g.Wo * ys) + (px & 31) * ys) * p.ldy + c) * 2) : BUF_OOB;
     }
-    {  // halo: slot sl = (quad, segment, pixel in quad)
-      const int hp = 8 * (id - 16) + 4 * (sl >> 3) + (sl & 3), sgm = (sl >> 2) & 1;
-      hir[j] = hp / HWD;
-      hjc[j] = hp - hir[j] * HWD;
+    {  // halo: slot sl = (quad, segment, pixel in quad); stride 2: (parity, segment, pixel pair)
+      const int hp = 8 * (id - ND) + (STR == 2 ? 2 * (sl & 3) + (sl >> 3) : 4 * (sl >> 3) + (sl & 3)), sgm = (sl >> 2) & 1;
+      hir[j] = hp / HWS;
+      hjc[j] = hp - hir[j] * HWS;
       hc[j] = n0 + sgm * 32 + ci * 8;
+      if (hp >= HPXS) hc[j] = 0x40000000;  // (beyond the halo: never in range)
     }
   }
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)dsm);
@@ -430,7 +440,7 @@ __global__ __launch_bounds__(NT) void wgrad3_dma_bf16_kernel(vae_wgrad_args p, i
   }
   auto request = [&](int buf) {  // the three pieces of the next unit into stage `buf`; beyond the range: descriptors of size 0 (zeros)
     const bool valid = nleft_ > 0;
-    const int b = nb_, y0 = nty_ * TH, x0 = ntx_ * TW;
+    const int b = nb_, y0 = nty_ * UTH, x0 = ntx_ * TW;
     --nleft_;
     if (++ntx_ == tiles_x) {
       ntx_ = 0;
@@ -449,7 +459,7 @@ __global__ __launch_bounds__(NT) void wgrad3_dma_bf16_kernel(vae_wgrad_args p, i
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "s"(dst), "v"(off), "s"(rsY) : "memory");
       } else {
-        const int hy = y0 - 1 + hir[j], hx = x0 - 1 + hjc[j];
+        const int hy = STR == 2 ? 2 * y0 + hir[j] : y0 - 1 + hir[j], hx = STR == 2 ? 2 * x0 + hjc[j] : x0 - 1 + hjc[j];
         const bool ok = kind[j] == 1 && ((unsigned)hy < (unsigned)Hb) && ((unsigned)hx < (unsigned)Wb) && hc[j] < p.N;
         const int sy = UP ? (hy >> 1) : hy, sx = UP ? (hx >> 1) : hx;
         const unsigned off = ok ? (unsigned)(((sy * g.Ws + sx) * g.Cs + hc[j]) * 2) : BUF_OOB;
@@ -465,11 +475,17 @@ __global__ __launch_bounds__(NT) void wgrad3_dma_bf16_kernel(vae_wgrad_args p, i
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) aoffb[mi] = lh * 2048 + trq * 256 + (((mt * 2 + mi) + trq) & 3) * 64 + trh * 32 + trp * 8;
   // halo: pixel hp = L + C,  L = tg*34 + 8 lh + trq,  C = r*34 + c0 + t (+ 4): address of L + m for m = 0..3, + 512 (C >> 2)
+  // (stride 2: L = tg*65 + 2 (8 lh + trq), C = 32 kg + t (+ 8): address of L + m for m = 0..2, + 1024 (C >> 3))
   int boffb[4];
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
-    const int hp = tg * HWD + lh * 8 + trq + m;
-    boffb[m] = 16 * 1024 + (hp >> 2) * 512 + nt * 256 + (hp & 3) * 64 + trh * 32 + trp * 8;
+    if (STR == 2) {
+      const int hp = tg * HWS + 2 * (lh * 8 + trq) + m;
+      boffb[m] = ND * 1024 + (hp >> 3) * 1024 + (((hp & 1) * 2 + nt) * 4 + ((hp >> 1) & 3)) * 64 + trh * 32 + trp * 8;
+    } else {
+      const int hp = tg * HWD + lh * 8 + trq + m;
+      boffb[m] = ND * 1024 + (hp >> 2) * 512 + nt * 256 + (hp & 3) * 64 + trh * 32 + trp * 8;
+    }
   }
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
   auto tr8 = [&](const unsigned char* lo, const unsigned char* hi) {
@@ -484,6 +500,7 @@ __global__ __launch_bounds__(NT) void wgrad3_dma_bf16_kernel(vae_wgrad_args p, i
   };
   auto fetch_b = [&](const unsigned char* st, int grp) {
     const int kg = grp / 3, t = grp - kg * 3;
+    if (STR == 2) return tr8(st + boffb[t] + kg * 4096, st + boffb[t] + kg * 4096 + 1024);
     const int C = (kg >> 1) * HWD + (kg & 1) * 16 + t;
     return tr8(st + boffb[C & 3] + (C >> 2) * 512, st + boffb[C & 3] + ((C >> 2) + 1) * 512);
   };
@@ -492,9 +509,9 @@ __global__ __launch_bounds__(NT) void wgrad3_dma_bf16_kernel(vae_wgrad_args p, i
     fetch_a(st, 0, fa[0]);
     fb[0] = fetch_b(st, 0);
 #pragma unroll
-    for (int grp = 0; grp < 12; ++grp) {
+    for (int grp = 0; grp < 3 * NKG; ++grp) {
       const int kg = grp / 3, t = grp - kg * 3;
-      if (grp + 1 < 12) {
+      if (grp + 1 < 3 * NKG) {
         if (t == 2) fetch_a(st, kg + 1, fa[(kg + 1) & 1]);
         fb[(grp + 1) & 1] = fetch_b(st, grp + 1);
       }
@@ -513,7 +530,7 @@ __global__ __launch_bounds__(NT) void wgrad3_dma_bf16_kernel(vae_wgrad_args p, i
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int q = tid + NT * i, px = q >> 4, cg = q & 15;  // 8-column group cg = segment cg >> 2, 16-byte chunk cg & 3
-    bofs[i] = q < UPX * 16 ? (px >> 2) * 1024 + (px & 3) * 256 + ((((cg >> 2) + px) & 3) * 64) + (cg & 3) * 16 : -1;
+    bofs[i] = q < UPXS * 16 ? (px >> 2) * 1024 + (px & 3) * 256 + ((((cg >> 2) + px) & 3) * 64) + (cg & 3) * 16 : -1;
   }
   auto bias_sums = [&](const unsigned char* st) {
 #pragma unroll
@@ -582,8 +599,19 @@ __global__ __launch_bounds__(NT) void wgrad3_dma_bf16_kernel(vae_wgrad_args p, i
 
 }  // namespace
 
+bool wgrad3_tile_bf16_dma(const vae_wgrad_args& a);
+// the stride-2 downsampler convolutions (3x3, padding (0,1,0,1)) on the LDS-DMA kernel: 1 x 32-pixel units
+static bool wgrad3_s2_geom(const vae_wgrad_args& a) {
+  const vae_conv_geom& g = a.g;
+  return g.mode == VAE_MODE_FWD && g.taps == 9 && g.stride == 2 && g.pad_t == 0 && g.pad_l == 0 && g.Hs == 2 * g.Ho && g.Ws == 2 * g.Wo &&
+         a.tapmask == 0 && a.y_step <= 1;
+}
 bool wgrad3_tile_bf16_eligible(const vae_wgrad_args& a, bool vec) {
   const vae_conv_geom& g = a.g;
+  if (vec && a.batch == 1 && wgrad3_s2_geom(a)) {
+    if (!wgrad3_tile_bf16_dma(a) || a.M <= 32 || a.N % BNT != 0 || g.Wo % TW != 0) return false;
+    return (size_t)g.Ho * g.Wo * a.ldy * 4u < BUF_MAX && (size_t)g.Hs * g.Ws * g.Cs * 4u < BUF_MAX;
+  }
   if (!vec || a.batch != 1 || g.taps != 9 || g.stride != 1 || g.pad_t != 1 || g.pad_l != 1) return false;
   if (a.M <= 32 || a.N % BNT != 0 || g.Wo % TW != 0 || g.Ho % TH != 0) return false;
   if (g.mode == VAE_MODE_FWD && !(g.Ho == g.Hs && g.Wo == g.Ws)) return false;
@@ -601,7 +629,7 @@ bool wgrad3_tile_bf16_dma(const vae_wgrad_args& a) {
   if (a.M % 8 != 0 || a.ldy % 8 != 0 || g.Cs % 8 != 0 || !aligned16(a.X16) || !aligned16(a.dY16)) return false;
   return true;
 }
-int64_t wgrad3_tile_bf16_units(const vae_conv_geom& g) { return (int64_t)g.B * (g.Ho / TH) * (g.Wo / TW); }
+int64_t wgrad3_tile_bf16_units(const vae_conv_geom& g) { return (int64_t)g.B * (g.stride == 2 ? g.Ho : g.Ho / TH) * (g.Wo / TW); }
 int wgrad3_tile_bf16_columns(const vae_wgrad_args& a) { return ((a.M + BMT - 1) / BMT) * (a.N / BNT); }
 
 int launch_wgrad3_tile_bf16(const vae_wgrad_args& a, hipStream_t st) {
@@ -614,16 +642,16 @@ int launch_wgrad3_tile_bf16(const vae_wgrad_args& a, hipStream_t st) {
 #define WG3(UPV, XFV, X16V) do { if (y16) hipLaunchKernelGGL((wgrad3_tile_bf16_kernel<UPV, XFV, X16V, true>), grid, dim3(NT), 0, st, a, tx, ty, nunits); \
                                 else hipLaunchKernelGGL((wgrad3_tile_bf16_kernel<UPV, XFV, X16V, false>), grid, dim3(NT), 0, st, a, tx, ty, nunits); } while (0)
   if (wgrad3_tile_bf16_dma(a)) {  // both operands as bf16 images: staged by LDS-DMA
-    static bool attr_set[2] = {false, false};
-    auto kern = up ? wgrad3_dma_bf16_kernel<true> : wgrad3_dma_bf16_kernel<false>;
-    if (!attr_set[up]) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS) != hipSuccess) {
-        vae_set_error("wgrad3_dma_bf16: cannot reserve %d bytes of LDS", DMA_LDS);
-        return VAE_ELAUNCH;
-      }
-      attr_set[up] = true;
+    if (g.stride == 2) {
+      VAE_RESERVE_LDS((wgrad3_dma_bf16_kernel<false, 2>), DMA_LDS, "wgrad3_dma_bf16");
+      hipLaunchKernelGGL((wgrad3_dma_bf16_kernel<false, 2>), grid, dim3(NT), DMA_LDS, st, a, tx, g.Ho, nunits);
+    } else if (up) {
+      VAE_RESERVE_LDS((wgrad3_dma_bf16_kernel<true, 1>), DMA_LDS, "wgrad3_dma_bf16");
+      hipLaunchKernelGGL((wgrad3_dma_bf16_kernel<true, 1>), grid, dim3(NT), DMA_LDS, st, a, tx, ty, nunits);
+    } else {
+      VAE_RESERVE_LDS((wgrad3_dma_bf16_kernel<false, 1>), DMA_LDS, "wgrad3_dma_bf16");
+      hipLaunchKernelGGL((wgrad3_dma_bf16_kernel<false, 1>), grid, dim3(NT), DMA_LDS, st, a, tx, ty, nunits);
     }
-    hipLaunchKernelGGL(kern, grid, dim3(NT), DMA_LDS, st, a, tx, ty, nunits);
     return 0;
   }
   if (a.X16 != nullptr) {  // transformed bf16 activation image (xf == NONE checked by the caller)
