@@ -11,6 +11,8 @@
 // Wave (mt, nt, kh) owns co rows mt*64.. (two 32-row blocks), ci columns nt*32.. and filter row kh: 3 taps x 2 co blocks = 6
 // accumulators.  Per 16-pixel k-group it reads 2 dY fragments (shared by its 3 taps) and 3 halo fragments for 6 MFMAs (5 KB;
 // the earlier 32 co x 64 ci split read 1 + 6 = 7 KB for the same 6 MFMAs).
+// Two kernels: wgrad3_tile_bf16_kernel stages through registers (any storage combination, fused GroupNorm / SiLU of X); wgrad3_dma_bf16_kernel
+// (further down; both operands as bf16 images, stride 1 or 2) stages by LDS-DMA into swizzled images -- what a bf16 step runs.
 #include "bf16_frag.h"
 
 namespace {
