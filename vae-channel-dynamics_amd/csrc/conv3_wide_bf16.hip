@@ -31,6 +31,7 @@
 
 namespace {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int BK = 32, TH = 8, TW = 32, HW_ = TW + 2, HROWS = TH + 2, HP = HROWS * HW_;  // 340 halo pixels
 constexpr int LDH = BK + 8;        // halo pixel stride in bf16 (80 B: conflict-free 16-byte row reads)
 constexpr int SH = HP * LDH;       // one halo buffer (13600 bf16 = 27200 B)
@@ -286,6 +287,16 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
 #endif
   while (true) {
     TSTAMP(0);
+    // the bias of the lane's channel pair, both channel blocks, requested BEFORE the tile's main loop: requested in the epilogue its
+    // L2 round trip stood in front of the first store of every tile with nothing to hide it (one wave per SIMD) -- half of what
+    // "bias + statistics" cost a 128-channel forward launch (16 tiles per workgroup)
+    float pbe[2], pbo[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int col = cur.n0 + wn * 64 + ni * 32 + lr;
+      pbe[ni] = (p.bias && col < p.N) ? p.bias[col & ~1] : 0.f;
+      pbo[ni] = (p.bias && col < p.N) ? p.bias[col | 1] : 0.f;
+    }
     if constexpr (KS == 3) {  // 3 stages per chunk: the stage parity repeats every 2 chunks (the launcher checks nch % 2 == 0)
       for (int c = 0; c < nch; c += 2) {
         stage(kw0_c, p0);
@@ -328,17 +339,11 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
       const auto rsC16 = VAE_BUF_RSRC(reinterpret_cast<u16*>(p.C) + (int64_t)cur.b * (g.Ho * cs) * (g.Wo * cs) * p.ldc, ob16);
       const auto rsR16 = VAE_BUF_RSRC(reinterpret_cast<const u16*>(p.res ? p.res : p.C) + (int64_t)cur.b * (g.Ho * cs) * (g.Wo * cs) * p.ldc, ob16);
       const unsigned pstep = (unsigned)(cs * p.ldc * 2);  // bytes per pixel step of the row grid
-      // the bias of the lane pair's channels, both channel blocks: loaded ONCE per tile, before the first store.  (Loaded per
-      // 16-pixel block, each load sat behind the previous block's stores and its wait -- vmcnt counts stores too -- made every
-      // block wait for the write acknowledgements of the one before: 8 store round trips per tile, 10 of a 128-channel tile's 42
-      // thousand cycles, also without a bias: the wait stays when the load is branched around.)
-      float pb0[2], pb1[2];
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        const int col = cur.n0 + wn * 64 + ni * 32 + lr;
-        pb0[ni] = (p.bias && col < p.N) ? p.bias[col & ~1] : 0.f;
-        pb1[ni] = (p.bias && col < p.N) ? p.bias[col | 1] : 0.f;
-      }
+      // (the bias: once per tile, see the top of the tile loop.  Loaded per 16-pixel block, each load sat behind the previous block's
+      // stores and its wait -- vmcnt counts stores too -- made every block wait for the write acknowledgements of the one before)
+      const float pb0[2] = {pbe[0], pbe[1]}, pb1[2] = {pbo[0], pbo[1]};
+      f32x2 sv1[2] = {{0.f, 0.f}, {0.f, 0.f}}, sv2[2] = {{0.f, 0.f}, {0.f, 0.f}};  // statistics: shifted sums of the lane's 64 values per channel block
+      float spv[2] = {0.f, 0.f};
       auto epi16 = [&](auto res_c, auto gst_c, auto wide_c) {
         constexpr bool RES = decltype(res_c)::value, GST = decltype(gst_c)::value, WIDE = decltype(wide_c)::value;
         static_assert(!(RES && WIDE), "the residual is added before the rounding, in the 4-byte layout");
@@ -389,12 +394,14 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
               h[1] = (__bf16)v1;
               P[j] = __builtin_bit_cast(unsigned, h);
               if constexpr (!WIDE) __builtin_amdgcn_raw_buffer_store_b32(P[j], rsC16, off2(r, ni, j), 0, 0);
-              if constexpr (GST) {
+              if constexpr (GST) {  // ONE pivot for the lane's 64 values of a channel block (its first), two independent chains of sums
                 const float q0 = (float)h[0], q1 = (float)h[1];
-                if (j == 0) gpv[r][ni] = q0;
-                const float d0 = q0 - gpv[r][ni], d1 = q1 - gpv[r][ni];  // (the statistics epilogue only runs on full tiles)
-                gs1[r][ni] += d0 + d1;
-                gs2[r][ni] += d0 * d0 + d1 * d1;
+                if (r == 0 && j == 0) spv[ni] = q0;
+                const float d0 = q0 - spv[ni], d1 = q1 - spv[ni];  // (the statistics epilogue only runs on full tiles)
+                sv1[ni][0] += d0;
+                sv1[ni][1] += d1;
+                sv2[ni][0] = fmaf(d0, d0, sv2[ni][0]);
+                sv2[ni][1] = fmaf(d1, d1, sv2[ni][1]);
               }
               acc[r][ni][2 * j] = 0.f;
               acc[r][ni][2 * j + 1] = 0.f;
@@ -435,6 +442,12 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
       } else {
         if (p.gstat) epi16(no, yes, no); else epi16(no, no, no);
       }
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {  // (the rows of a channel block are already merged: slot 0 carries all 64 values)
+        gpv[0][ni] = spv[ni];
+        gs1[0][ni] = sv1[ni][0] + sv1[ni][1];
+        gs2[0][ni] = sv2[ni][0] + sv2[ni][1];
+      }
     } else {
       // fp32 output (+ bias, + residual).  The residual is HBM-cold: its loads are issued for HALF of the wave's tile (two
       // rows x two channel blocks, 64 registers) before any of them is consumed -- with one wave per SIMD nothing else hides
@@ -446,12 +459,8 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
           return (col < p.N && oy < g.Ho && ox < g.Wo) ? (unsigned)((((oy * cs + p.c_oy) * (g.Wo * cs) + ox * cs + p.c_ox) * p.ldc + col) * 4) : BUF_OOB;
         return (col < p.N && oy < g.Ho && ox < g.Wo) ? (unsigned)(((oy * g.Wo + ox) * p.ldc + col) * 4) : BUF_OOB;
       };
-      float pbv[2];  // (once per tile, before the first store: see the bf16 branch)
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        const int col = cur.n0 + wn * 64 + ni * 32 + lr;
-        pbv[ni] = (p.bias && col < p.N) ? p.bias[col] : 0.f;
-      }
+      const bool oddl = lr & 1;
+      const float pbv[2] = {oddl ? pbo[0] : pbe[0], oddl ? pbo[1] : pbe[1]};  // (once per tile: see the top of the tile loop)
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         float rv[4][16];
@@ -494,11 +503,17 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
       float* gbase = p.gstat + (((int64_t)cur.b * (tiles_x * tiles_y) + tile_in_img) * 2 + wm) * p.gstat_groups * 2;
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
-        const MeanM2 r01 = mm2_merge_equal(mm2_from_shifted(gpv[0][ni], gs1[0][ni], gs2[0][ni], 16.f),
-                                           mm2_from_shifted(gpv[1][ni], gs1[1][ni], gs2[1][ni], 16.f), 16.f);
-        const MeanM2 r23 = mm2_merge_equal(mm2_from_shifted(gpv[2][ni], gs1[2][ni], gs2[2][ni], 16.f),
-                                           mm2_from_shifted(gpv[3][ni], gs1[3][ni], gs2[3][ni], 16.f), 16.f);
-        const MeanM2 a = mm2_wave_group(mm2_merge_equal(r01, r23, 32.f), cpg, 64.f);
+        MeanM2 lane64;
+        if (p.out_bf16) {  // uniform: one set of shifted sums over the lane's 64 values
+          lane64 = mm2_from_shifted(gpv[0][ni], gs1[0][ni], gs2[0][ni], 64.f);
+        } else {
+          const MeanM2 r01 = mm2_merge_equal(mm2_from_shifted(gpv[0][ni], gs1[0][ni], gs2[0][ni], 16.f),
+                                             mm2_from_shifted(gpv[1][ni], gs1[1][ni], gs2[1][ni], 16.f), 16.f);
+          const MeanM2 r23 = mm2_merge_equal(mm2_from_shifted(gpv[2][ni], gs1[2][ni], gs2[2][ni], 16.f),
+                                             mm2_from_shifted(gpv[3][ni], gs1[3][ni], gs2[3][ni], 16.f), 16.f);
+          lane64 = mm2_merge_equal(r01, r23, 32.f);
+        }
+        const MeanM2 a = mm2_wave_group(lane64, cpg, 64.f);
         if (lh == 0 && (lr & (cpg - 1)) == 0) {
           float* o = gbase + ((cur.n0 + wn * 64 + ni * 32 + lr) / cpg) * 2;
           o[0] = a.m;
