@@ -26,6 +26,9 @@
 // tap-MACs per low-resolution pixel are computed, none masked), operand pixel (y,x) at (y*a_step+a_oy, x*a_step+a_ox) of the
 // image, output pixel at (y*c_step+c_oy, x*c_step+c_ox).
 #include "bf16_frag.h"
+#ifndef VAE_ABLATE
+#define VAE_ABLATE 0
+#endif
 #include <algorithm>
 #include <type_traits>
 
@@ -253,10 +256,12 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
           }
           fetch_b(fb[0], q, sBn, 0);
         }
-        if (pi < NW) w_load_piece(PAR, pi);                                       // stage +3
-        if (pi >= 2 * NPK - NW) w_store_piece(PAR ^ 1, pi - (2 * NPK - NW), sBw);  // stage +2, requested a stage and a half ago
-        if (KWI == 0 && pi < HI) h_load_piece(pi);
-        if (KWI == 1 && pi >= 2 * NPK - HI) h_store_piece(pi - (2 * NPK - HI), sHw);
+        // (VAE_ABLATE: diagnostic builds of tools/ablation_builds.sh, wrong results -- bit 0 no weight loads, 1 no weight LDS stores,
+        // 2 no halo loads, 3 no halo LDS stores, 4 no barrier: what the staging costs)
+        if (!(VAE_ABLATE & 1) && pi < NW) w_load_piece(PAR, pi);                                       // stage +3
+        if (!(VAE_ABLATE & 2) && pi >= 2 * NPK - NW) w_store_piece(PAR ^ 1, pi - (2 * NPK - NW), sBw);  // stage +2, requested a stage and a half ago
+        if (!(VAE_ABLATE & 4) && KWI == 0 && pi < HI) h_load_piece(pi);
+        if (!(VAE_ABLATE & 8) && KWI == 1 && pi >= 2 * NPK - HI) h_store_piece(pi - (2 * NPK - HI), sHw);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -266,7 +271,7 @@ __global__ __launch_bounds__(NT, 1) void conv3_wide_bf16_kernel(vae_igemm_args p
     ringB[0] = ringB[1];
     ringB[1] = ringB[2];
     ringB[2] = t0;
-    __syncthreads();
+    if (!(VAE_ABLATE & 16)) __syncthreads();
     if (KS == 2 && KWI == KS - 1) {
 #pragma unroll
       for (int j = 0; j < NA; ++j) fetch_a(fa[0], j, sHn, KWN, 0);

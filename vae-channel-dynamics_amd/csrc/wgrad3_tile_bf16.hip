@@ -14,6 +14,9 @@
 // Two kernels: wgrad3_tile_bf16_kernel stages through registers (any storage combination, fused GroupNorm / SiLU of X); wgrad3_dma_bf16_kernel
 // (further down; both operands as bf16 images, stride 1 or 2) stages by LDS-DMA into swizzled images -- what a bf16 step runs.
 #include "bf16_frag.h"
+#ifndef VAE_ABLATE
+#define VAE_ABLATE 0  // diagnostic builds (tools/ablation_builds.sh, wrong results): bit 0 no global loads / DMA pieces fetch nothing, 1 no LDS stores, 4 no barrier
+#endif
 
 namespace {
 
@@ -290,11 +293,11 @@ __global__ __launch_bounds__(NT) void wgrad3_tile_bf16_kernel(vae_wgrad_args p, 
       compute(cA, cA + SA, 0, 6);
       {  // staged in the shadow of the MFMAs already issued; unconditional (see load_regs)
         u16* nA = smem + ((s + 1) & 1) * STAGE;
-        store_lds(nA, nA + SA);
-        load_regs();
+        if (!(VAE_ABLATE & 2)) store_lds(nA, nA + SA);
+        if (!(VAE_ABLATE & 1)) load_regs();
       }
       compute(cA, cA + SA, 6, 12);
-      __syncthreads();
+      if (!(VAE_ABLATE & 16)) __syncthreads();
     }
   }
 
@@ -417,7 +420,7 @@ __global__ __launch_bounds__(NT) void wgrad3_dma_bf16_kernel(vae_wgrad_args p, i
   for (int j = 0; j < 3; ++j) {
     const int id = wave * 3 + j;
     const int sl = lane >> 2, ci = lane & 3;
-    kind[j] = id < ND ? 0 : (id < ND + NH ? 1 : 2);
+    kind[j] = (VAE_ABLATE & 1) ? 2 : (id < ND ? 0 : (id < ND + NH ? 1 : 2));  // (ablation: every piece out of range, same instructions)
     {  // dY: slot sl of the piece = pixel q = sl >> 2, bank range sl & 3 -> segment ((sl & 3) - q) & 3
       const int q = sl >> 2, sg = ((sl & 3) - q) & 3;
       const int px = 4 * (id % ND) + q, c = m0 + sg * 32 + ci * 8;

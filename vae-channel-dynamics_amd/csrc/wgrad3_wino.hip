@@ -19,6 +19,9 @@
 // Numerics: measured against the direct kernel in tests/test_kernels_gpu.py (the transform-domain sums cancel in the output
 // transform, so the error is a few 1e-6 of the gradient scale instead of 1e-7; the parity bar is 1e-4).
 #include "common.h"
+#ifndef VAE_ABLATE
+#define VAE_ABLATE 0  // diagnostic builds (tools/ablation_builds.sh, wrong results): bit 0 no global loads, 1 no LDS stores, 4 no barrier
+#endif
 #include <algorithm>
 #include <type_traits>
 
@@ -243,17 +246,17 @@ __global__ __launch_bounds__(GNT, 1) void wgrad3_wino_kernel(vae_wgrad_args p, i
         build_b(rd, bb[0]);
         read_d(1, rd);
       }
-      if (wave < 4) store_unit(nst, cur);  // the two waves of a SIMD store at opposite ends of the step
+      if (!(VAE_ABLATE & 2) && wave < 4) store_unit(nst, cur);  // the two waves of a SIMD store at opposite ends of the step
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb) {
         __builtin_amdgcn_sched_barrier(0);
         if (nb == 1) {  // the requests for unit k+2 (index counters + 4 loads) behind the first block's MFMAs, not in front of the
           // step, where both waves of a SIMD build operands and the matrix pipe has nothing to do (2.1-2.7 % of the kernel)
-          load_unit(k + 2, nxt);
+          if (!(VAE_ABLATE & 1)) load_unit(k + 2, nxt);
           __builtin_amdgcn_sched_barrier(0);
         }
         if (nb == 3 && wave >= 4) {  // (waves 4..7: the LDS stores of unit k+1 behind the third block's MFMAs, not between the last MFMA and the barrier)
-          store_unit(nst, cur);
+          if (!(VAE_ABLATE & 2)) store_unit(nst, cur);
           __builtin_amdgcn_sched_barrier(0);
         }
         if (nb < 3) build_b(rd, bb[(nb + 1) & 1]);  // block nb+1's operands, during the first half of this block's MFMAs
@@ -271,7 +274,7 @@ __global__ __launch_bounds__(GNT, 1) void wgrad3_wino_kernel(vae_wgrad_args p, i
         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
-      __syncthreads();
+      if (!(VAE_ABLATE & 16)) __syncthreads();
     };
     int k = 0;
     for (; k + 1 < nu; k += 2) {
