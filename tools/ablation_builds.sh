@@ -5,7 +5,7 @@
 #   kernel's halo loads / stores, 16 no barrier.          usage (GPU box): bash tools/ablation_builds.sh [wide|wgrad16|wgrad32]
 set -e
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; C=$R/vae-channel-dynamics_amd/csrc; O=$R/gpurun_out/ablation; mkdir -p $O
-FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-result"
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -Xclang -target-feature -Xclang -packed-fp32-ops -Wno-unused-result"
 OBJS=$(make -C $C -pn 2>/dev/null | sed -n 's/^OBJS = //p' | head -1)
 run() {  # kernel source, bits, microbench command
   local src=$1 bits=$2; shift 2
