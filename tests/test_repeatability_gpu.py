@@ -95,3 +95,33 @@ def test_fp32_kernels_repeat_bitwise(cuda):
             out["gnb"] = dx._gnb[0].clone()
         return out
     _compare(run, 500)
+
+
+@pytest.mark.parametrize("prec,B,R,steps", [("bf16", 4, 256, 40), ("no", 2, 256, 20)])
+def test_whole_step_repeats_bitwise(cuda, prec, B, R, steps):
+    """forward + loss + backward from the same parameters and inputs, repeated: the gradient arena (83.65 M values) and the loss
+    scalars must come out bit for bit the same every time"""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "vae-channel-dynamics_amd", "src"))
+    from models.sdxl_vae_wrapper import SDXLVAEWrapper
+    w = SDXLVAEWrapper("synthetic:7", device=cuda)
+    eng = w.vae.engine
+    eng.set_precision(prec)
+    try:
+        gen = torch.Generator(device=cuda).manual_seed(1)
+        x = torch.rand((B, 3, R, R), device=cuda, generator=gen) * 2 - 1
+        eps = torch.randn((B, 4, R // 8, R // 8), device=cuda, generator=gen)
+        ref = None
+        for it in range(steps):
+            res = eng.forward_backward(x, eps, 1e-6)
+            g, sc = w.vae.arena.grad, res["scalars"]
+            if ref is None:
+                ref = (g.clone(), sc.clone())
+                assert bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0
+            else:
+                assert torch.equal(sc, ref[1]), f"step {it}: loss scalars differ"
+                assert torch.equal(g, ref[0]), f"step {it}: {int((g != ref[0]).sum())} gradient values differ"
+    finally:
+        eng.set_precision("no")
